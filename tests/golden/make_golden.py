@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Generate the golden input/output vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the builder container (``/root/reference`` does not exist on the GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+It imports ``/root/reference/model/{attention,pspnet,bisenet}.py`` and ``evaluation.py`` on CPU.
+Three kinds of absent third-party modules are shimmed *before* import:
+
+1. ``localAttention`` (zzd1992/Image-Local-Attention, CUDA, not vendored): the forward pair is
+   provided with zero-padded ``F.unfold`` exactly as the reference's own in-tree restatements do
+   (model/attention.py:56-58, 77-85).  This is the one boundary whose parity is not pinned by
+   reference-executed code (see oracle/cpu_ref.py header); ``f_weighting_cpu`` (in-tree, runnable)
+   is additionally recorded as an independent pin for ``weighting_forward``.
+2. ``torchvision`` / ``cv2`` (imported, unused on this path) -> empty stubs.
+3. ``torch.utils.model_zoo.load_url`` (network download of ImageNet weights) -> ``{}``.
+
+Only data is written: seeded inputs, the reference's outputs, and a manifest of state_dict keys /
+shapes / a SHA-256 of the synthetic weights.  Weights are regenerated from (seed, key, shape) by
+``arseg_amd.synth`` and never committed.  No reference source text is stored.
+"""
+import hashlib
+import importlib
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+torch.set_num_threads(8)
+
+from arseg_amd import synth  # noqa: E402
+
+
+# ----------------------------------------------------------------------------------------------
+# shims
+# ----------------------------------------------------------------------------------------------
+def _unfold(x, kH, kW):
+    N, C, H, W = x.shape
+    return F.unfold(x, kernel_size=(kH, kW), padding=(kH // 2, kW // 2)).view(N, C, kH * kW, H, W)
+
+
+def _similar_forward(x_ori, x_loc, kH, kW):
+    return (x_ori.unsqueeze(2) * _unfold(x_loc, kH, kW)).sum(dim=1).permute(0, 2, 3, 1).contiguous()
+
+
+def _weighting_forward(x_ori, x_weight, kH, kW):
+    return (_unfold(x_ori, kH, kW) * x_weight.permute(0, 3, 1, 2).unsqueeze(1)).sum(dim=2)
+
+
+def _raise(*a, **k):
+    raise NotImplementedError("backward of localAttention is outside the hot path")
+
+
+def install_shims():
+    la = types.ModuleType("localAttention")
+    la.similar_forward = _similar_forward
+    la.weighting_forward = _weighting_forward
+    la.similar_backward = la.weighting_backward_ori = la.weighting_backward_weight = _raise
+    sys.modules["localAttention"] = la
+
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return None
+
+        def __getattr__(self, n):
+            return _Any()
+
+    tv = stub("torchvision")
+    tv.models = stub("torchvision.models")
+    tv.models.densenet = stub("torchvision.models.densenet", densenet121=_Any)
+    tv.models.squeezenet = stub("torchvision.models.squeezenet", squeezenet1_1=_Any)
+    tv.transforms = stub("torchvision.transforms", Compose=_Any, ToTensor=_Any, Normalize=_Any, ColorJitter=_Any)
+    stub("cv2")
+    import torch.utils.model_zoo as mz
+
+    mz.load_url = lambda *a, **k: {}
+    sys.path.insert(0, REF)
+
+
+def save(name, **arrays):
+    out = {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()}
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def sd_manifest(module):
+    sd = module.state_dict()
+    h = hashlib.sha256()
+    for k, v in sd.items():
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(v.numpy()).tobytes())
+    return {"keys": [[k, list(v.shape)] for k, v in sd.items()], "sha256": h.hexdigest()}
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
+
+
+def main():
+    install_shims()
+    attention = importlib.import_module("model.attention")
+    pspnet = importlib.import_module("model.pspnet")
+    bisenet = importlib.import_module("model.bisenet")
+    evaluation = importlib.import_module("evaluation")
+    manifest = {"torch": torch.__version__}
+
+    with torch.no_grad():
+        # ---------------- G1 warpFeature (evaluation.py:61-87) ----------------
+        print("G1 warp")
+        for seed in (0, 1):
+            feat = rnd(100 + seed, 1, 8, 12, 16)
+            g = np.random.Generator(np.random.PCG64(200 + seed))
+            flow_int = torch.from_numpy(g.integers(-6, 7, (1, 12, 16, 2)).astype(np.float64))       # integer-pel, some OOB
+            flow_frac = torch.from_numpy(g.uniform(-20, 20, (1, 12, 16, 2)))                         # fractional f64, far OOB
+            flow_f32 = flow_frac.float()
+            zero = torch.zeros(1, 12, 16, 2, dtype=torch.float64)
+            save(f"g1_warp_s{seed}", feat=feat, flow_int=flow_int, flow_frac=flow_frac, flow_f32=flow_f32,
+                 out_int=evaluation.warpFeature(feat, flow_int), out_frac=evaluation.warpFeature(feat, flow_frac),
+                 out_f32=evaluation.warpFeature(feat, flow_f32), out_zero=evaluation.warpFeature(feat, zero))
+
+        # ---------------- G2 MV resize block (evaluation.py:176-180) ----------------
+        print("G2 mv resize")
+        for seed in (0, 1):
+            g = np.random.Generator(np.random.PCG64(300 + seed))
+            mvq = g.integers(-40, 41, (1, 32, 48, 2)).astype(np.int16) * 4
+            flow = torch.from_numpy(mvq.astype(np.float64) / 4)                                      # camvid.py:625
+            outs = {}
+            for (hp, wp) in ((4, 6), (32, 48), (5, 7)):
+                f = flow.transpose(2, 3).transpose(1, 2)
+                f = f * hp / f.shape[-2]
+                f = F.interpolate(f, [hp, wp], mode="bilinear", align_corners=True)
+                outs[f"out_{hp}x{wp}"] = f.transpose(1, 2).transpose(2, 3)
+            save(f"g2_mvresize_s{seed}", mvq=mvq, **outs)
+
+        # ---------------- G3 MyAttention + the localAttention pair ----------------
+        print("G3 MyAttention")
+        cases = [(8, (10, 12), (5, 6), 7), (64, (10, 12), (5, 6), 7), (8, (7, 9), (3, 4), 7), (16, (9, 11), (9, 11), 5),
+                 (8, (4, 5), (2, 3), 7)]
+        for ci, (C, hw, lhw, k) in enumerate(cases):
+            for seed in (0, 1):
+                m = attention.MyAttention(C, kW=k, kH=k).eval()
+                synth.load_synth_weights(m, seed, attn_gain=(0.35 if seed == 0 else 1.0))
+                hr = rnd(400 + 10 * ci + seed, 1, C, *hw)
+                lr = rnd(500 + 10 * ci + seed, 1, C, *lhw)
+                out = m(hr, lr)
+                save(f"g3_attn_c{ci}_s{seed}", hr=hr, lr=lr, out=out, k=k,
+                     **{"w." + kk: vv for kk, vv in m.state_dict().items()})
+        manifest["MyAttention64"] = sd_manifest(synth.load_synth_weights(attention.MyAttention(64, kW=7, kH=7), 0))
+        # in-tree CPU restatement of weighting_forward (attention.py:75-85): independent pin
+        v = rnd(600, 2, 6, 9, 8)
+        w = torch.softmax(rnd(601, 2, 9, 8, 35), dim=3)
+        q = rnd(602, 2, 6, 9, 8)
+        save("g3_pair", v=v, w=w, q=q, weighting_cpu=attention.f_weighting_cpu(v, w, 5, 7),
+             weighting_shim=_weighting_forward(v, w, 5, 7), similar_shim=_similar_forward(q, v, 5, 7), kH=5, kW=7)
+
+        # ---------------- G4 PSPNet.forward (pspnet.py:76-100) ----------------
+        print("G4 PSPNet")
+        hr_net = pspnet.PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256,
+                               backend="resnet18", pretrained=False).eval()
+        synth.load_synth_weights(hr_net, 0)
+        manifest["PSPNet"] = sd_manifest(hr_net)
+        x = rnd(700, 1, 3, 48, 64)
+        out, cls, p_hr = hr_net(x)
+        save("g4_pspnet", x=x, out=out, cls=cls, p=p_hr)
+
+        # ---------------- G5 PSPNetWithFuse phase1/phase2 (pspnet.py:198-231) ----------------
+        print("G5 PSPNetWithFuse")
+        lr_net = pspnet.PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256,
+                                       backend="resnet18", pretrained=False, atten_k=7).eval()
+        synth.load_synth_weights(lr_net, 1)
+        manifest["PSPNetWithFuse"] = sd_manifest(lr_net)
+        xl = rnd(701, 1, 3, 24, 32)
+        cls1, p1 = lr_net.forward_phase1(xl)
+        out2, p2 = lr_net.forward_phase2(p1, p_hr)
+        outn, clsn, pn = lr_net(xl, mode="normal")
+        outm, clsm, pm = lr_net(xl, mode="merge", ref_p=p_hr)
+        save("g5_pspfuse", x=xl, cls1=cls1, p1=p1, out2=out2, p2=p2, out_normal=outn, cls_normal=clsn,   # ref_p = g4_pspnet.p
+             p_normal_s2=pn[..., ::2, ::2], merge_equal=np.array([torch.equal(outm, out2), torch.equal(pm, p2)]))
+
+        # ---------------- G6 BiSeNetV1 / BiSeNetV1WithFuse (bisenet.py:419-575) ----------------
+        print("G6 BiSeNet")
+        bhr = bisenet.BiSeNetV1(n_classes=12, backend="resnet18").eval()
+        synth.load_synth_weights(bhr, 2)
+        manifest["BiSeNetV1"] = sd_manifest(bhr)
+        xb = rnd(800, 1, 3, 64, 128)
+        o, o16, o32, fuse = bhr(xb)
+        save("g6_bisenet", x=xb, out=o, out16_s4=o16[..., ::4, ::4], out32_s4=o32[..., ::4, ::4], feat_fuse=fuse)
+        blr = bisenet.BiSeNetV1WithFuse(n_classes=12, backend="resnet18").eval()
+        synth.load_synth_weights(blr, 3)
+        manifest["BiSeNetV1WithFuse"] = sd_manifest(blr)
+        xbl = rnd(801, 1, 3, 32, 64)
+        a16, a32, mid = blr.forward_phase1(xbl)
+        ob, pb = blr.forward_phase2(mid, fuse)
+        save("g6_bisefuse", x=xbl, ref_p=fuse, aux16_s4=a16[..., ::4, ::4], aux32_s4=a32[..., ::4, ::4], mid=mid, out=ob, p=pb)
+        xodd = rnd(802, 1, 3, 67, 131)                                           # feat8 9x17 vs 2*feat16 10x18 -> re-interpolation
+        a16o, a32o, mido = blr.forward_phase1(xodd)
+        oo, o16o, o32o, fo = bhr(xodd)
+        save("g6_biseodd", x=xodd, mid=mido, aux16_s4=a16o[..., ::4, ::4], hr_out_s2=oo[..., ::2, ::2], hr_feat_fuse=fo)
+
+        # ---------------- G7 one EvalAlterRes step (evaluation.py:148-215) ----------------
+        print("G7 EvalAlterRes")
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+
+        class Wrap:  # stands in for nn.DataParallel: callable + .module (evaluation.py:173,190)
+            def __init__(self, m):
+                self.module = m
+
+            def __call__(self, *a, **k):
+                return self.module(*a, **k)
+
+        for kind, hr_m, lr_m, H, W, mean, std in (("psp", hr_net, lr_net, 48, 64, synth.CAMVID_MEAN, synth.CAMVID_STD),
+                                                  ("bise", bhr, blr, 64, 128, synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)):
+            clip = synth.make_clip(7, H, W, gop=4, mean=mean, std=std)
+            img = torch.from_numpy(clip["frames"][3:4])
+            ref = torch.from_numpy(clip["frames"][0:1])
+            mvq = clip["mv"][3:4]
+            flow = torch.from_numpy(mvq.astype(np.float64) / 4)
+            g = np.random.Generator(np.random.PCG64(900))
+            label = torch.from_numpy(g.integers(0, 12, (1, H, W)).astype(np.int64))
+            label[0, :3, :5] = 255
+            captured = {}
+            orig_p2 = lr_m.forward_phase2
+
+            def spy(p, ref_p, _o=orig_p2):
+                r = _o(p, ref_p)
+                captured["warped"], captured["out"], captured["p"] = ref_p, r[0], r[1]
+                return r
+
+            lr_m.forward_phase2 = spy
+            miou = evaluation.EvalAlterRes(scale=0.5)(Wrap(hr_m), Wrap(lr_m), [(img, label, None, ref, flow)], 12)
+            lr_m.forward_phase2 = orig_p2
+            logits = F.interpolate(captured["out"], size=label.shape[-2:], mode="bilinear", align_corners=True)
+            preds = torch.argmax(torch.softmax(logits, dim=1), dim=1)
+            keep = label != 255
+            hist = torch.bincount(label[keep] * 12 + preds[keep], minlength=144).view(12, 12).float()
+            save(f"g7_alter_{kind}", img=img, ref=ref, mvq=mvq, label=label, warped=captured["warped"], out=captured["out"],
+                 p_s2=captured["p"][..., ::2, ::2], preds=preds, hist=hist, miou=np.float64(miou))
+            # EvalConstRes on the HR net (keyframe path, evaluation.py:90-144)
+            miou_c = evaluation.EvalConstRes(scale=1.0)(Wrap(hr_m), [(ref, label, None)], 12)
+            manifest[f"g7_{kind}_miou_const"] = float(miou_c)
+
+    with open(os.path.join(HERE, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=0, sort_keys=True)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()

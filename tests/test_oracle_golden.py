@@ -1,0 +1,133 @@
+"""Pins the oracle (oracle/cpu_ref.py, oracle/local_attn_ref.c) against golden vectors produced by the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import maxdiff, sd_from_manifest, t
+from oracle import c_ref, cpu_ref
+
+TOL = 1e-5  # oracle vs reference-generated golden
+
+
+def test_synth_weights_match_manifest_hash(manifest):
+    for name, seed in (("PSPNet", 0), ("PSPNetWithFuse", 1), ("BiSeNetV1", 2), ("BiSeNetV1WithFuse", 3), ("MyAttention64", 0)):
+        sd = sd_from_manifest(manifest, name, seed)
+        h = hashlib.sha256()
+        for k, v in sd.items():
+            h.update(k.encode())
+            h.update(np.ascontiguousarray(v.numpy()).tobytes())
+        assert h.hexdigest() == manifest[name]["sha256"], name
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_g1_warp(golden, seed):
+    g = golden(f"g1_warp_s{seed}")
+    feat = t(g["feat"])
+    for k in ("int", "frac", "f32"):
+        assert maxdiff(cpu_ref.warp_feature(feat, t(g[f"flow_{k}"])), g[f"out_{k}"]) <= TOL
+    zero = torch.zeros(1, 12, 16, 2, dtype=torch.float64)
+    assert maxdiff(cpu_ref.warp_feature(feat, zero), g["out_zero"]) <= TOL
+    # zero motion is NOT an identity warp (align_corners mismatch)
+    assert maxdiff(g["out_zero"], g["feat"]) > 1e-2
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_g2_mv_resize(golden, seed):
+    g = golden(f"g2_mvresize_s{seed}")
+    flow = cpu_ref.mv_from_int16(t(g["mvq"]))
+    for hp, wp in ((4, 6), (32, 48), (5, 7)):
+        out = cpu_ref.mv_resize(flow, hp, wp)
+        assert out.dtype == torch.float64
+        assert maxdiff(out, g[f"out_{hp}x{wp}"]) <= 1e-12
+
+
+@pytest.mark.parametrize("ci", range(5))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_g3_my_attention(golden, ci, seed):
+    g = golden(f"g3_attn_c{ci}_s{seed}")
+    sd = {k[2:]: t(g[k]) for k in g.files if k.startswith("w.")}
+    k = int(g["k"])
+    out = cpu_ref.my_attention(sd, "", t(g["hr"]), t(g["lr"]), k, k)
+    assert maxdiff(out, g["out"]) <= TOL
+
+
+def test_g3_local_attention_pair(golden):
+    g = golden("g3_pair")
+    kH, kW = int(g["kH"]), int(g["kW"])
+    v, w, q = t(g["v"]), t(g["w"]), t(g["q"])
+    # weighting: pinned by the reference's in-tree f_weighting_cpu (attention.py:75-85)
+    assert maxdiff(cpu_ref.local_weighting(v, w, kH, kW), g["weighting_cpu"]) <= TOL
+    assert maxdiff(c_ref.local_weighting(g["v"], g["w"], kH, kW), g["weighting_cpu"]) <= TOL
+    assert maxdiff(g["weighting_shim"], g["weighting_cpu"]) <= TOL
+    # similar: contract from attention.py:56-64 comments (parity unpinned w.r.t. the absent CUDA op)
+    assert maxdiff(cpu_ref.local_similar(q, v, kH, kW), g["similar_shim"]) <= TOL
+    assert maxdiff(c_ref.local_similar(g["q"], g["v"], kH, kW), g["similar_shim"]) <= TOL
+
+
+def test_g4_pspnet(golden, manifest):
+    g = golden("g4_pspnet")
+    sd = sd_from_manifest(manifest, "PSPNet", 0)
+    out, cls, p = cpu_ref.pspnet_forward(sd, t(g["x"]))
+    assert maxdiff(p, g["p"]) <= 5e-5
+    assert maxdiff(out, g["out"]) <= 5e-5
+    assert maxdiff(cls, g["cls"]) <= 5e-5
+
+
+def test_g5_pspnet_with_fuse(golden, manifest):
+    g = golden("g5_pspfuse")
+    ref_p = t(golden("g4_pspnet")["p"])
+    sd = sd_from_manifest(manifest, "PSPNetWithFuse", 1)
+    cls1, p1 = cpu_ref.pspnet_fuse_phase1(sd, t(g["x"]))
+    assert maxdiff(cls1, g["cls1"]) <= 5e-5 and maxdiff(p1, g["p1"]) <= 5e-5
+    out2, p2 = cpu_ref.pspnet_fuse_phase2(sd, t(g["p1"]), ref_p)
+    assert maxdiff(out2, g["out2"]) <= 5e-5 and maxdiff(p2, g["p2"]) <= 5e-5
+    outn, clsn, pn = cpu_ref.pspnet_forward(sd, t(g["x"]))
+    assert maxdiff(outn, g["out_normal"]) <= 5e-5 and maxdiff(pn[..., ::2, ::2], g["p_normal_s2"]) <= 5e-5
+    assert bool(g["merge_equal"].all())
+
+
+def test_g6_bisenet(golden, manifest):
+    g = golden("g6_bisenet")
+    sd = sd_from_manifest(manifest, "BiSeNetV1", 2)
+    out, o16, o32, fuse = cpu_ref.bisenet_forward(sd, t(g["x"]))
+    assert maxdiff(out, g["out"]) <= 5e-5
+    assert maxdiff(o16[..., ::4, ::4], g["out16_s4"]) <= 5e-5
+    assert maxdiff(o32[..., ::4, ::4], g["out32_s4"]) <= 5e-5
+    assert maxdiff(fuse, g["feat_fuse"]) <= 5e-5
+    # odd sizes: feat8 (9x17) != 2*feat16 (10x18) -> the re-interpolation branches (bisenet.py:298,442)
+    go = golden("g6_biseodd")
+    oo, _, _, fo = cpu_ref.bisenet_forward(sd, t(go["x"]))
+    assert maxdiff(oo[..., ::2, ::2], go["hr_out_s2"]) <= 5e-5 and maxdiff(fo, go["hr_feat_fuse"]) <= 5e-5
+
+
+def test_g6_bisenet_with_fuse(golden, manifest):
+    g = golden("g6_bisefuse")
+    sd = sd_from_manifest(manifest, "BiSeNetV1WithFuse", 3)
+    a16, a32, mid = cpu_ref.bisenet_fuse_phase1(sd, t(g["x"]))
+    assert maxdiff(mid, g["mid"]) <= 5e-5
+    assert maxdiff(a16[..., ::4, ::4], g["aux16_s4"]) <= 5e-5 and maxdiff(a32[..., ::4, ::4], g["aux32_s4"]) <= 5e-5
+    out, p = cpu_ref.bisenet_fuse_phase2(sd, t(g["mid"]), t(g["ref_p"]))
+    assert maxdiff(out, g["out"]) <= 5e-5 and maxdiff(p, g["p"]) <= 5e-5
+    go = golden("g6_biseodd")
+    a16o, _, mido = cpu_ref.bisenet_fuse_phase1(sd, t(go["x"]))
+    assert maxdiff(mido, go["mid"]) <= 5e-5 and maxdiff(a16o[..., ::4, ::4], go["aux16_s4"]) <= 5e-5
+
+
+@pytest.mark.parametrize("kind,hr_name,hr_seed,lr_name,lr_seed", [("psp", "PSPNet", 0, "PSPNetWithFuse", 1),
+                                                                   ("bise", "BiSeNetV1", 2, "BiSeNetV1WithFuse", 3)])
+def test_g7_alter_res_step(golden, manifest, kind, hr_name, hr_seed, lr_name, lr_seed):
+    g = golden(f"g7_alter_{kind}")
+    sd_hr = sd_from_manifest(manifest, hr_name, hr_seed)
+    sd_lr = sd_from_manifest(manifest, lr_name, lr_seed)
+    flow = cpu_ref.mv_from_int16(t(g["mvq"]))
+    out, p, warped, _ = cpu_ref.alter_res_step(kind, sd_hr, sd_lr, t(g["img"]), t(g["ref"]), flow, 0.5)
+    assert maxdiff(warped, g["warped"]) <= 5e-5
+    assert maxdiff(out, g["out"]) <= 1e-4
+    assert maxdiff(p[..., ::2, ::2], g["p_s2"]) <= 1e-4
+    preds, hist = cpu_ref.eval_tail(out, t(g["label"]), 12)
+    assert (preds.numpy() != g["preds"]).mean() <= 1e-3          # argmax ties at 1e-5 noise only
+    assert abs(float(cpu_ref.miou(t(g["hist"]))) - float(g["miou"])) <= 1e-6
+    assert float((hist - t(g["hist"])).abs().sum()) <= 4
