@@ -1,0 +1,94 @@
+"""ctypes binding of libarseg_hip.so (the C ABI declared in include/arseg_hip.h).
+
+The library is the product: if it is missing or a symbol is absent this module raises -- there
+is no Python / PyTorch fallback for any op.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libarseg_hip.so")
+
+ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
+NCHW, NHWC, C8 = 0, 1, 2
+FLOW_F32, FLOW_F64 = 0, 1
+NEAREST, BILINEAR = 0, 1
+REDUCE_MEAN, REDUCE_MAX = 0, 1
+
+
+class ConvDesc(Structure):
+    """struct arseg_conv_desc (include/arseg_hip.h)."""
+    _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("in_ld", c_int),
+                ("Cout", c_int), ("out_ld", c_int), ("res_ld", c_int),
+                ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
+                ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int)]
+
+
+_P = c_void_p  # device or host pointer passed as integer
+_STREAM = c_void_p
+
+# name -> (restype, argtypes); must list every function of include/arseg_hip.h (tests check this)
+PROTOTYPES = {
+    "arseg_version": (c_int, []),
+    "arseg_status_string": (c_char_p, [c_int]),
+    "arseg_local_similar_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_local_weighting_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_warp_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_mv_resize_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_warp_mvq_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_creff_fwd": (c_int, [_P] * 8 + [_P, _P, _P, c_int, _P, c_int] + [c_int] * 8 + [_STREAM]),
+    "arseg_to_c8_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _STREAM]),
+    "arseg_from_c8_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_conv_out_hw": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
+    "arseg_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
+    "arseg_packed_k": (c_int, [c_int, c_int, c_int]),
+    "arseg_pack_conv_weight_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "arseg_fold_bn_host": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, _P, _P]),
+    "arseg_pack_dw3x3_host": (c_int, [_P, c_int, _P]),
+    "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_global_reduce_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_resize_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),
+    "arseg_scale_add_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _STREAM]),
+    "arseg_head_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_frame_to_nhwc4_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_nchw_to_nhwc_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_nhwc_to_nchw_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _STREAM]),
+    "arseg_argmax_confusion_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_STREAM]),
+}
+
+_lib = None
+
+
+class ArsegError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the shared library (once).  Raises if it has not been built -- see __graft_entry__.build()."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ArsegError(f"{LIB_PATH} is missing: build it with `make -C ar-seg_amd/csrc` "
+                         f"(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI and this binding drifted apart
+        fn.restype, fn.argtypes = res, args
+    if lib.arseg_version() != 1:
+        raise ArsegError(f"ABI version mismatch: library reports {lib.arseg_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str) -> None:
+    if status == ARSEG_OK:
+        return
+    msg = load().arseg_status_string(int(status)).decode()
+    raise ArsegError(f"{what} failed: status {status} ({msg})")

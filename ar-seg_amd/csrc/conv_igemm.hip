@@ -1,0 +1,388 @@
+// conv2d as an implicit GEMM on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces the nn.Conv2d / BatchNorm2d / ReLU / PReLU stacks of the reference backbones
+// (model/extractors.py:35-66,108-158; model/pspnet.py:14-46; model/bisenet.py:31-60,162-399).
+//
+//   GEMM view      M = N*Ho*Wo output pixels, N = Cout, K = R*S*Cin (k = (r*S+s)*Cin + ci)
+//   A (activations) NHWC: the K axis is channel-contiguous, so a 16-byte vector never straddles a
+//                   filter tap; im2col is done by address arithmetic in the loader (zero fill for
+//                   padding), nothing is materialised.
+//   B (weights)     packed [Cout][Kpad] (K contiguous) by arseg_pack_conv_weight_host.
+//   Block           256 threads = 4 waves in a 2x2 grid, block tile BM x BN, K step 32.
+//   LDS             A and B tiles as [row][32+4] floats (the +4 pad makes the ds_read_b128 of a
+//                   32-row fragment conflict free), double buffered; one barrier per K step.
+//   Global -> LDS   register staged (16-byte loads issued before the MFMAs of the current step,
+//                   written to the other buffer after them) because im2col needs predication.
+//   MFMA fragments  lane l = (i = l&31, h = l>>5) reads 4 consecutive k (one ds_read_b128) for row i
+//                   at k-offset 8*k8+4*h; the 4 values feed 4 MFMAs.  The MFMA's two k slots (h=0,1)
+//                   therefore see k = 8*k8+kk and 8*k8+4+kk -- a permutation of K applied
+//                   identically to A and B, which leaves the product unchanged.
+//   Epilogue        y = acc*scale[co] + bias[co] (+ residual) -> none/ReLU/PReLU/sigmoid, NHWC store
+//                   (32 consecutive channels per half wave = 128-byte segments).
+//   Split-K         gridDim.z slices of the K loop write fp32 partials to the workspace; a second
+//                   kernel sums them in slice order (deterministic) and applies the epilogue.
+//   XCD mapping     the linear block id is remapped so that each of the 8 XCDs (private L2) gets a
+//                   contiguous run of tiles that share activation rows.
+#include "arseg_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDS_LD = BK + 4;
+
+struct ConvParams {
+    const float *in, *w, *scale, *bias, *res;
+    float *out, *ws;
+    int N, H, W, Cin, in_ld, log2Cin;
+    int Ho, Wo, Cout, out_ld, res_ld;
+    int R, S, stride, pad, dil;
+    int K, Kpad, M;
+    int act;
+    float slope;
+    int ktiles, ktiles_per_split, nsplit;
+    int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+    switch (act) {
+        case ARSEG_ACT_RELU: return fmaxf(v, 0.0f);
+        case ARSEG_ACT_PRELU: return v >= 0.0f ? v : v * slope;
+        case ARSEG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave (wave tile BM/2 x BN/2)
+    constexpr int RA = BM / 32, RB = BN / 32;     // rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *As = smem;                              // [2][BM][LDS_LD]
+    float *Bs = smem + 2 * BM * LDS_LD;            // [2][BN][LDS_LD]
+
+    // XCD-aware (bijective) remap of the linear block id: XCD x gets a contiguous chunk of tiles.
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;   // n fastest: neighbours share A rows
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x;
+    const int col4 = tid & 7;          // which 16-byte vector of the 32-float K step
+    const int row0 = tid >> 3;         // 0..31
+
+    // decode the output pixels this thread stages (constant over the K loop)
+    int iy0[RA], ix0[RA], pbase[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int m = m0 + row0 + 32 * i;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.stride - p.pad;
+            ix0[i] = ox * p.stride - p.pad;
+            pbase[i] = n * p.H * p.W;
+        } else {
+            iy0[i] = -(1 << 28); ix0[i] = 0; pbase[i] = 0;     // every tap fails the bounds test
+        }
+    }
+
+    const int kt_begin = blockIdx.z * p.ktiles_per_split;
+    const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
+
+    f32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + col4 * 4;
+        int c, dy = 0, dx = 0;
+        bool kvalid;
+        if (p.R * p.S == 1) { c = k; kvalid = k < p.K; }
+        else {
+            const int rs = k >> p.log2Cin;
+            c = k & (p.Cin - 1);
+            kvalid = rs < p.R * p.S;
+            const int r = rs / p.S, s = rs - r * p.S;
+            dy = r * p.dil; dx = s * p.dil;
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *reinterpret_cast<const f32x4 *>(p.in + (size_t)(pbase[i] + iy * p.W + ix) * p.in_ld + c);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int n = n0 + row0 + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.Cout) v = *reinterpret_cast<const f32x4 *>(p.w + (size_t)n * p.Kpad + k);
+            rb[i] = v;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(a + (row0 + 32 * i) * LDS_LD + col4 * 4) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(b + (row0 + 32 * i) * LDS_LD + col4 * 4) = rb[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+        const float *a = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
+        const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+        for (int k8 = 0; k8 < BK / 8; ++k8) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const f32x4 *>(a + t * 32 * LDS_LD + k8 * 8);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fb[t] = *reinterpret_cast<const f32x4 *>(b + t * 32 * LDS_LD + k8 * 8);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn)
+                        acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][kk], fb[tn][kk], acc[tm][tn], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / 2) + tn * 32 + li;
+            if (n >= p.Cout) continue;
+            float sc = 1.0f, bi = 0.0f;
+            if (p.nsplit == 1) {
+                if (p.scale) sc = p.scale[n];
+                if (p.bias) bi = p.bias[n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= p.M) continue;
+                float v = acc[tm][tn][r];
+                if (p.nsplit == 1) {
+                    v = v * sc + bi;
+                    if (p.res) v += p.res[(size_t)m * p.res_ld + n];
+                    p.out[(size_t)m * p.out_ld + n] = apply_act(v, p.act, p.slope);
+                } else {
+                    p.ws[((size_t)blockIdx.z * p.M + m) * p.Cout + n] = v;
+                }
+            }
+        }
+}
+
+// sums the split-K partials in slice order and applies the epilogue; 4 channels per thread
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
+    const int c4 = p.Cout >> 2;
+    const long long total = (long long)p.M * c4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / c4), n = (int)(idx - (long long)m * c4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(p.ws + (size_t)m * p.Cout + n);
+        for (int z = 1; z < p.nsplit; ++z) v += *reinterpret_cast<const f32x4 *>(p.ws + ((size_t)z * p.M + m) * p.Cout + n);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j] * (p.scale ? p.scale[n + j] : 1.0f) + (p.bias ? p.bias[n + j] : 0.0f);
+            if (p.res) x += p.res[(size_t)m * p.res_ld + n + j];
+            p.out[(size_t)m * p.out_ld + n + j] = apply_act(x, p.act, p.slope);
+        }
+    }
+}
+
+struct Plan { int bm, bn, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
+
+int make_plan(const arseg_conv_desc *d, Plan *pl) {
+    if (!d) return ARSEG_EINVAL;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->R <= 0 || d->S <= 0 || d->stride <= 0 ||
+        d->dil <= 0 || d->pad < 0)
+        return ARSEG_EINVAL;
+    if ((d->Cin & 3) || (d->in_ld & 3) || d->in_ld < d->Cin || d->out_ld < d->Cout) return ARSEG_EINVAL;
+    if (d->R * d->S > 1 && (d->Cin & (d->Cin - 1))) return ARSEG_EUNSUPPORTED;
+    pl->Ho = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
+    pl->Wo = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
+    if (pl->Ho <= 0 || pl->Wo <= 0) return ARSEG_EINVAL;
+    const long long M = (long long)d->N * pl->Ho * pl->Wo;
+    if (M > (1ll << 30) || (long long)d->N * d->H * d->W > (1ll << 30)) return ARSEG_EUNSUPPORTED;
+    pl->M = (int)M;
+    pl->K = d->R * d->S * d->Cin;
+    pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
+    pl->ktiles = pl->Kpad / BK;
+
+    static const int cfg[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
+    int bm, bn;
+    if (d->tile_cfg >= 1 && d->tile_cfg <= 4) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
+    else {
+        // largest tile that still gives >= 2 blocks per CU (256 CUs); small problems fall to 64x64 (+ split-K)
+        const int order[4] = {1, 2, 4, 3};
+        bm = 64; bn = 64;
+        for (int t = 0; t < 4; ++t) {
+            const int tb_m = cfg[order[t]][0], tb_n = cfg[order[t]][1];
+            if (tb_n == 128 && d->Cout <= 64) continue;
+            if (tb_m == 128 && M <= 64) continue;
+            const long long blocks = (long long)arseg_cdiv(M, tb_m) * arseg_cdiv(d->Cout, tb_n);
+            if (blocks >= 512) { bm = tb_m; bn = tb_n; break; }
+        }
+    }
+    pl->bm = bm; pl->bn = bn;
+    pl->tiles_m = arseg_cdiv(M, bm);
+    pl->tiles_n = arseg_cdiv(d->Cout, bn);
+    int nsplit = d->split_k;
+    if (nsplit <= 0) {
+        const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
+        nsplit = 1;
+        if (blocks < 384) {
+            nsplit = (int)((512 + blocks - 1) / blocks);
+            const int max_by_k = pl->ktiles / 8 > 0 ? pl->ktiles / 8 : 1;   // keep >= 8 K steps per slice
+            if (nsplit > max_by_k) nsplit = max_by_k;
+            if (nsplit > 16) nsplit = 16;
+        }
+    }
+    if (nsplit > pl->ktiles) nsplit = pl->ktiles;
+    if (nsplit > 1 && (d->Cout & 3)) nsplit = 1;   // the reduce kernel is 4-wide
+    pl->ktiles_per_split = arseg_cdiv(pl->ktiles, nsplit);
+    pl->nsplit = arseg_cdiv(pl->ktiles, pl->ktiles_per_split);
+    return ARSEG_OK;
+}
+
+template <int BM, int BN>
+int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
+    const size_t smem = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    static bool attr_set = false;     // idempotent; a race only repeats the same call
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_f32_kernel<BM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.nsplit);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN>), grid, dim3(256), smem, st, p);
+    return arseg_launch_status();
+}
+
+}  // namespace
+
+extern "C" int arseg_packed_k(int Cin_pad, int R, int S) {
+    const int K = R * S * Cin_pad;
+    return (K + BK - 1) / BK * BK;
+}
+
+extern "C" int arseg_conv_out_hw(const arseg_conv_desc *d, int *Ho, int *Wo) {
+    Plan pl;
+    int st = make_plan(d, &pl);
+    if (st != ARSEG_OK) return st;
+    if (Ho) *Ho = pl.Ho;
+    if (Wo) *Wo = pl.Wo;
+    return ARSEG_OK;
+}
+
+extern "C" size_t arseg_conv2d_workspace_bytes(const arseg_conv_desc *d) {
+    Plan pl;
+    if (make_plan(d, &pl) != ARSEG_OK) return 0;
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * pl.M * d->Cout * sizeof(float) : 0;
+}
+
+extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale,
+                                const float *bias, const float *residual, float *out, void *workspace,
+                                size_t workspace_bytes, arseg_stream_t stream) {
+    Plan pl;
+    int st = make_plan(d, &pl);
+    if (st != ARSEG_OK) return st;
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(w_packed); ARSEG_CHECK_PTR(out);
+    if (!ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(w_packed)) return ARSEG_EINVAL;
+    if (residual && d->res_ld < d->Cout) return ARSEG_EINVAL;
+    if (pl.nsplit > 1) {
+        if (!workspace || workspace_bytes < (size_t)pl.nsplit * pl.M * d->Cout * sizeof(float)) return ARSEG_EWORKSPACE;
+        if (!ARSEG_ALIGNED16(workspace)) return ARSEG_EINVAL;
+    }
+    ConvParams p;
+    p.in = in; p.w = w_packed; p.scale = scale; p.bias = bias; p.res = residual; p.out = out;
+    p.ws = reinterpret_cast<float *>(workspace);
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld;
+    p.log2Cin = 0;
+    while ((1 << p.log2Cin) < d->Cin) ++p.log2Cin;
+    p.Ho = pl.Ho; p.Wo = pl.Wo; p.Cout = d->Cout; p.out_ld = d->out_ld; p.res_ld = d->res_ld;
+    p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.K = pl.K; p.Kpad = pl.Kpad; p.M = pl.M;
+    p.act = d->act; p.slope = d->prelu_slope;
+    p.ktiles = pl.ktiles; p.ktiles_per_split = pl.ktiles_per_split; p.nsplit = pl.nsplit;
+    p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+    hipStream_t hs = arseg_stream(stream);
+    if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128>(p, pl, hs);
+    else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64>(p, pl, hs);
+    else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128>(p, pl, hs);
+    else st = launch<64, 64>(p, pl, hs);
+    if (st != ARSEG_OK) return st;
+    if (pl.nsplit > 1) {
+        const long long total = (long long)pl.M * (d->Cout >> 2);
+        int blocks = arseg_cdiv(total, 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(blocks), dim3(256), 0, hs, p);
+        st = arseg_launch_status();
+    }
+    return st;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side weight packer
+// ---------------------------------------------------------------------------------------------
+extern "C" int arseg_pack_conv_weight_host(const float *w, int Cout, int Cin, int R, int S, int Cin_pad, float *out) {
+    if (!w || !out || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || Cin_pad < Cin || (Cin_pad & 3)) return ARSEG_EINVAL;
+    const int Kpad = arseg_packed_k(Cin_pad, R, S);
+    for (int co = 0; co < Cout; ++co) {
+        float *o = out + (size_t)co * Kpad;
+        for (int k = 0; k < Kpad; ++k) o[k] = 0.0f;
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int r = 0; r < R; ++r)
+                for (int s = 0; s < S; ++s) o[(r * S + s) * Cin_pad + ci] = w[(((size_t)co * Cin + ci) * R + r) * S + s];
+    }
+    return ARSEG_OK;
+}
+
+extern "C" int arseg_fold_bn_host(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                                  const float *conv_bias, int C, float *scale_out, float *bias_out) {
+    if (!gamma || !beta || !mean || !var || !scale_out || !bias_out || C <= 0) return ARSEG_EINVAL;
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)gamma[c] / sqrt((double)var[c] + (double)eps);
+        scale_out[c] = (float)s;
+        bias_out[c] = (float)((double)beta[c] + ((conv_bias ? (double)conv_bias[c] : 0.0) - (double)mean[c]) * s);
+    }
+    return ARSEG_OK;
+}
+
+extern "C" int arseg_pack_dw3x3_host(const float *w, int C, float *out) {
+    if (!w || !out || C <= 0) return ARSEG_EINVAL;
+    for (int c = 0; c < C; ++c)
+        for (int t = 0; t < 9; ++t) out[(size_t)t * C + c] = w[(size_t)c * 9 + t];
+    return ARSEG_OK;
+}

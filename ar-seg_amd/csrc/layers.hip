@@ -1,0 +1,395 @@
+// The small NHWC layers around the conv engine: pooling, global reductions, resizes (every
+// align_corners / nearest flavour the reference uses), ARM/FFM channel scaling, the 1x1 classifier
+// head, frame ingest (downscale + NCHW -> NHWC4), layout changes and the evaluator tail.
+// All of them are HBM/L2-bound element-wise or small-window kernels: 16-byte channel vectors per
+// lane (coalesced along C), grid-stride loops, no MFMA.
+#include "arseg_common.h"
+
+namespace {
+
+inline int grid_for(long long total, int cap = 8192) {
+    long long b = (total + 255) / 256;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// ------------------------------------------------------------------ MaxPool2d(3, 2, 1)
+__global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restrict__ in, float *__restrict__ out, int N,
+                                                           int H, int W, int C, int Ho, int Wo) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Ho * Wo * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long long pix = idx / c4n;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho), n = (int)(pix / ((long long)Wo * Ho));
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)n * H + iy) * W + ix) * C + c);
+                m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * C + c) = m;
+    }
+}
+
+// ------------------------------------------------------------------ adaptive avg pool / global mean / global max
+// block = (bin, 64-channel chunk, n); 256 threads = 16 pixel lanes x 16 channel vectors; LDS tree over pixel lanes.
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
+                                                            int H, int W, int C, int oh, int ow) {
+    __shared__ f32x4 red[16][17];
+    const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
+    const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
+    const int x0 = (bx * W) / ow, x1 = ((bx + 1) * W + ow - 1) / ow;
+    const int cv = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.y * 64 + cv * 4;
+    const int ww = x1 - x0, cnt = (y1 - y0) * ww;
+    f32x4 acc = IS_MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int i = pl; i < cnt; i += 16) {
+            const int yy = y0 + i / ww, xx = x0 + i % ww;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)n * H + yy) * W + xx) * in_ld + c);
+            if (IS_MAX) { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
+            else acc += v;
+        }
+    }
+    red[pl][cv] = acc;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+        f32x4 t = red[0][cv];
+        for (int i = 1; i < 16; ++i) {
+            const f32x4 v = red[i][cv];
+            if (IS_MAX) { t[0] = fmaxf(t[0], v[0]); t[1] = fmaxf(t[1], v[1]); t[2] = fmaxf(t[2], v[2]); t[3] = fmaxf(t[3], v[3]); }
+            else t += v;
+        }
+        if (!IS_MAX) t = t / (float)cnt;
+        *reinterpret_cast<f32x4 *>(out + ((size_t)n * oh * ow + bin) * C + c) = t;
+    }
+}
+
+// ------------------------------------------------------------------ resize
+__global__ __launch_bounds__(256) void resize_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int C,
+                                                          int Hin, int Win, int Hout, int Wout, int mode, int align, int in_ld,
+                                                          int out_ld) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * Hout * Wout * c4n;
+    const float sy = arseg_resize_scale(Hin, Hout, align), sx = arseg_resize_scale(Win, Wout, align);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long long pix = idx / c4n;
+        const int ox = (int)(pix % Wout), oy = (int)((pix / Wout) % Hout), n = (int)(pix / ((long long)Wout * Hout));
+        const float *base = in + (size_t)n * Hin * Win * in_ld + c;
+        f32x4 v;
+        if (mode == ARSEG_NEAREST) {
+            const int iy = min((int)floorf((float)oy * ((float)Hin / (float)Hout)), Hin - 1);
+            const int ix = min((int)floorf((float)ox * ((float)Win / (float)Wout)), Win - 1);
+            v = *reinterpret_cast<const f32x4 *>(base + ((size_t)iy * Win + ix) * in_ld);
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(sy, oy, align, Hin, y0, y1, ly);
+            arseg_src_index(sx, ox, align, Win, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(base + ((size_t)y0 * Win + x0) * in_ld);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(base + ((size_t)y0 * Win + x1) * in_ld);
+            const f32x4 cc = *reinterpret_cast<const f32x4 *>(base + ((size_t)y1 * Win + x0) * in_ld);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(base + ((size_t)y1 * Win + x1) * in_ld);
+            v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * out_ld + c) = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void resize_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin,
+                                                          int Win, int Hout, int Wout, int mode, int align) {
+    const long long total = (long long)NC * Hout * Wout;
+    const float sy = arseg_resize_scale(Hin, Hout, align), sx = arseg_resize_scale(Win, Wout, align);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wout), oy = (int)((idx / Wout) % Hout);
+        const long long pc = idx / ((long long)Wout * Hout);
+        const float *base = in + (size_t)pc * Hin * Win;
+        float v;
+        if (mode == ARSEG_NEAREST) {
+            const int iy = min((int)floorf((float)oy * ((float)Hin / (float)Hout)), Hin - 1);
+            const int ix = min((int)floorf((float)ox * ((float)Win / (float)Wout)), Win - 1);
+            v = base[(size_t)iy * Win + ix];
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(sy, oy, align, Hin, y0, y1, ly);
+            arseg_src_index(sx, ox, align, Win, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+            v = (1.f - ly) * ((1.f - lx) * base[(size_t)y0 * Win + x0] + lx * base[(size_t)y0 * Win + x1]) +
+                ly * ((1.f - lx) * base[(size_t)y1 * Win + x0] + lx * base[(size_t)y1 * Win + x1]);
+        }
+        out[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------ ARM / FFM channel scaling
+__global__ __launch_bounds__(256) void scale_add_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                        const float *__restrict__ add_full, const float *__restrict__ add_vec,
+                                                        float *__restrict__ out, int N, int HW, int C) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * HW * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long long pix = idx / c4n;
+        const int n = (int)(pix / HW);
+        f32x4 v = *reinterpret_cast<const f32x4 *>(x + pix * C + c) * *reinterpret_cast<const f32x4 *>(scale + (size_t)n * C + c);
+        if (add_full) v += *reinterpret_cast<const f32x4 *>(add_full + pix * C + c);
+        if (add_vec) v += *reinterpret_cast<const f32x4 *>(add_vec + (size_t)n * C + c);
+        *reinterpret_cast<f32x4 *>(out + pix * C + c) = v;
+    }
+}
+
+// ------------------------------------------------------------------ 1x1 classifier head (NHWC in, NCHW out)
+template <int NC>
+__global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ p, int p_ld, const float *__restrict__ wf,
+                                                   const float *__restrict__ bf, float *__restrict__ logits, int N, int HW, int C,
+                                                   int n_cls, int log_softmax) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [n_cls][C]
+    for (int i = threadIdx.x; i < n_cls * C; i += blockDim.x) wsm[i] = wf[i];
+    __syncthreads();
+    const long long total = (long long)N * HW;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        float acc[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) acc[k] = (k < n_cls) ? bf[k] : 0.f;
+        const float *pp = p + pix * p_ld;
+        for (int c = 0; c < C; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(pp + c);
+#pragma unroll
+            for (int k = 0; k < NC; ++k)
+                if (k < n_cls) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wsm + k * C + c);
+                    acc[k] += v[0] * w[0] + v[1] * w[1] + v[2] * w[2] + v[3] * w[3];
+                }
+        }
+        if (log_softmax) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) if (k < n_cls) m = fmaxf(m, acc[k]);
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < NC; ++k) if (k < n_cls) s += expf(acc[k] - m);
+            const float lse = m + logf(s);
+#pragma unroll
+            for (int k = 0; k < NC; ++k) acc[k] -= lse;
+        }
+        const int n = (int)(pix / HW);
+        const long long hw = pix - (long long)n * HW;
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (k < n_cls) logits[((size_t)n * n_cls + k) * HW + hw] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------ frame ingest: NCHW RGB -> NHWC4 (+ downscale)
+__global__ __launch_bounds__(256) void frame_to_nhwc4_kernel(const float *__restrict__ img, float *__restrict__ out, int N, int H,
+                                                             int W, int h, int w) {
+    const long long total = (long long)N * h * w;
+    const float sy = arseg_resize_scale(H, h, true), sx = arseg_resize_scale(W, w, true);
+    const bool same = (h == H && w == W);
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(pix % w), oy = (int)((pix / w) % h), n = (int)(pix / ((long long)w * h));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float *base = img + (size_t)n * 3 * H * W;
+        if (same) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = base[(size_t)c * H * W + (size_t)oy * W + ox];
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(sy, oy, true, H, y0, y1, ly);
+            arseg_src_index(sx, ox, true, W, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *b = base + (size_t)c * H * W;
+                v[c] = (1.f - ly) * ((1.f - lx) * b[(size_t)y0 * W + x0] + lx * b[(size_t)y0 * W + x1]) +
+                       ly * ((1.f - lx) * b[(size_t)y1 * W + x0] + lx * b[(size_t)y1 * W + x1]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * 4) = v;
+    }
+}
+
+// ------------------------------------------------------------------ layout changes (LDS-tiled 32x32 transposes)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW,
+                                                           int out_ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, hw = hw0 + tx;
+        tile[j][tx] = (c < C && hw < HW) ? in[((size_t)n * C + c) * HW + hw] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int hw = hw0 + j, c = c0 + tx;
+        if (c < C && hw < HW) out[((size_t)n * HW + hw) * out_ld + c] = tile[tx][j];
+    }
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out, int C,
+                                                           int HW) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int hw = hw0 + j, c = c0 + tx;
+        tile[j][tx] = (c < C && hw < HW) ? in[((size_t)n * HW + hw) * in_ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, hw = hw0 + tx;
+        if (c < C && hw < HW) out[((size_t)n * C + c) * HW + hw] = tile[tx][j];
+    }
+}
+
+// ------------------------------------------------------------------ evaluator tail
+__global__ __launch_bounds__(256) void argmax_confusion_kernel(const float *__restrict__ logits, const int64_t *__restrict__ label,
+                                                               int32_t *__restrict__ pred, unsigned long long *__restrict__ hist,
+                                                               int N, int n_cls, int h, int w, int H, int W, int ignore_label) {
+    __shared__ unsigned int lh[1024];
+    for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const long long total = (long long)N * H * W;
+    const float sy = arseg_resize_scale(h, H, true), sx = arseg_resize_scale(w, W, true);
+    const bool same = (h == H && w == W);
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(pix % W), oy = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+        int y0 = oy, y1 = oy, x0 = ox, x1 = ox; float ly = 0.f, lx = 0.f;
+        if (!same) {
+            arseg_src_index(sy, oy, true, h, y0, y1, ly);
+            arseg_src_index(sx, ox, true, w, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+        }
+        float best = -INFINITY; int bi = 0;
+        for (int k = 0; k < n_cls; ++k) {
+            const float *b = logits + ((size_t)n * n_cls + k) * h * w;
+            float v;
+            if (same) v = b[(size_t)oy * w + ox];
+            else v = (1.f - ly) * ((1.f - lx) * b[(size_t)y0 * w + x0] + lx * b[(size_t)y0 * w + x1]) +
+                     ly * ((1.f - lx) * b[(size_t)y1 * w + x0] + lx * b[(size_t)y1 * w + x1]);
+            if (v > best) { best = v; bi = k; }
+        }
+        if (pred) pred[pix] = bi;
+        if (hist && label) {
+            const long long lab = label[pix];
+            if (lab != ignore_label && lab >= 0 && lab < n_cls) atomicAdd(&lh[(int)lab * n_cls + bi], 1u);
+        }
+    }
+    __syncthreads();
+    if (hist)
+        for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x)
+            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
+}  // namespace
+
+extern "C" int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    if (C & 3) return ARSEG_EINVAL;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((long long)N * Ho * Wo * (C >> 2))), dim3(256), 0, arseg_stream(stream),
+                       in, out, N, H, W, C, Ho, Wo);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int oh, int ow,
+                                          arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    ARSEG_CHECK_POS(oh); ARSEG_CHECK_POS(ow);
+    if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(window_reduce_kernel<false>, dim3(oh * ow, arseg_cdiv(C, 64), N), dim3(256), 0, arseg_stream(stream), in,
+                       in_ld, out, H, W, C, oh, ow);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op,
+                                       arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
+    dim3 grid(1, arseg_cdiv(C, 64), N);
+    if (op == ARSEG_REDUCE_MEAN)
+        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, H, W, C, 1, 1);
+    else if (op == ARSEG_REDUCE_MAX)
+        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, H, W, C, 1, 1);
+    else return ARSEG_EINVAL;
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_resize_fwd(const float *in, float *out, int N, int C, int Hin, int Win, int Hout, int Wout, int mode,
+                                int align_corners, int layout, int in_ld, int out_ld, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(Hin); ARSEG_CHECK_POS(Win);
+    ARSEG_CHECK_POS(Hout); ARSEG_CHECK_POS(Wout);
+    if (mode != ARSEG_NEAREST && mode != ARSEG_BILINEAR) return ARSEG_EINVAL;
+    if (layout == ARSEG_NHWC) {
+        if ((C & 3) || (in_ld & 3) || (out_ld & 3) || in_ld < C || out_ld < C) return ARSEG_EINVAL;
+        hipLaunchKernelGGL(resize_nhwc_kernel, dim3(grid_for((long long)N * Hout * Wout * (C >> 2))), dim3(256), 0,
+                           arseg_stream(stream), in, out, N, C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0, in_ld, out_ld);
+    } else if (layout == ARSEG_NCHW) {
+        hipLaunchKernelGGL(resize_nchw_kernel, dim3(grid_for((long long)N * C * Hout * Wout, 16384)), dim3(256), 0,
+                           arseg_stream(stream), in, out, N * C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0);
+    } else return ARSEG_EINVAL;
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_scale_add_fwd(const float *x, const float *scale, const float *add_full, const float *add_vec, float *out,
+                                   int N, int HW, int C, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(x); ARSEG_CHECK_PTR(scale); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(HW); ARSEG_CHECK_POS(C);
+    if (C & 3) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(scale_add_kernel, dim3(grid_for((long long)N * HW * (C >> 2))), dim3(256), 0, arseg_stream(stream), x, scale,
+                       add_full, add_vec, out, N, HW, C);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_head_fwd(const float *p, int p_ld, const float *wf, const float *bf, float *logits, int N, int HW, int C,
+                              int n_cls, int log_softmax, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(p); ARSEG_CHECK_PTR(wf); ARSEG_CHECK_PTR(bf); ARSEG_CHECK_PTR(logits);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(HW); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(n_cls);
+    if ((C & 3) || (p_ld & 3) || p_ld < C) return ARSEG_EINVAL;
+    if (n_cls > 32 || (size_t)n_cls * C * sizeof(float) > 60 * 1024) return ARSEG_EUNSUPPORTED;
+    const size_t smem = (size_t)n_cls * C * sizeof(float);
+    const int g = grid_for((long long)N * HW, 2048);
+    hipStream_t st = arseg_stream(stream);
+    if (n_cls <= 12) hipLaunchKernelGGL(head_kernel<12>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+    else if (n_cls <= 19) hipLaunchKernelGGL(head_kernel<19>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+    else hipLaunchKernelGGL(head_kernel<32>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_frame_to_nhwc4_fwd(const float *img, float *out, int N, int H, int W, int h, int w, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(img); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w);
+    hipLaunchKernelGGL(frame_to_nhwc4_kernel, dim3(grid_for((long long)N * h * w)), dim3(256), 0, arseg_stream(stream), img, out, N, H, W, h, w);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_nchw_to_nhwc_fwd(const float *in, float *out, int N, int C, int HW, int out_ld, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(HW);
+    if (out_ld < C) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(arseg_cdiv(HW, 32), arseg_cdiv(C, 32), N), dim3(256), 0, arseg_stream(stream), in, out, C, HW, out_ld);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(HW);
+    if (in_ld < C) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(arseg_cdiv(HW, 32), arseg_cdiv(C, 32), N), dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, HW);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_t *pred, int64_t *hist, int N, int n_cls,
+                                          int h, int w, int H, int W, int ignore_label, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(logits); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(n_cls); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
+    if (n_cls > 32) return ARSEG_EUNSUPPORTED;
+    if (!pred && !(hist && label)) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(argmax_confusion_kernel, dim3(grid_for((long long)N * H * W, 1024)), dim3(256), 0, arseg_stream(stream), logits,
+                       label, pred, reinterpret_cast<unsigned long long *>(hist), N, n_cls, h, w, H, W, ignore_label);
+    return arseg_launch_status();
+}

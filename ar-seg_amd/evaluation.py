@@ -1,0 +1,119 @@
+"""Hot-path pieces of the reference's ``evaluation.py`` on libarseg_hip.so.
+
+* ``warpFeature``      -- evaluation.py:61-87
+* ``resize_flow``      -- the MV resize block, evaluation.py:176-180
+* ``EvalConstRes`` / ``EvalAlterRes`` -- evaluation.py:90-144 / 148-215, same call signatures
+  (``dl`` is any iterable of the reference's sample tuples).  Networks may be bare modules or
+  wrapped in ``nn.DataParallel`` (the reference addresses ``net.module`` on the hot path).
+* ``alter_res_step_fast`` -- the same non-keyframe step on the kernel-native layouts (int16 MVs in,
+  fused MV-resize + warp writing C8, fused CReFF + head), used by the GOP runner and bench.py.
+
+The CLI / dataset walking of the reference (evaluation.py:218-439) needs the datasets and
+checkpoints and is out of scope.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib, ops
+
+
+def _unwrap(net):
+    return net.module if hasattr(net, "module") else net
+
+
+def warpFeature(feature, flow):
+    """feature [B,C,H,W] (NCHW-contiguous or channels_last), flow [B,H,W,2] float32/float64 in feature pixels."""
+    if ops.is_nhwc_view(feature) and not feature.is_contiguous():
+        return ops.as_nchw(ops.warp(ops.to_nhwc(feature), flow, _lib.NHWC))
+    return ops.warp(feature.contiguous(), flow, _lib.NCHW)
+
+
+def resize_flow(flow, Hp, Wp):
+    """evaluation.py:176-180 for a float flow [B,H,W,2] in pixels (any float dtype): both components are scaled by
+    Hp/H, then bilinear(align_corners=True).  The kernel works on the on-disk int16 quarter-pel representation, which
+    is exact for the reference's data (``flow = int16 / 4``, dataset/camvid.py:625)."""
+    q = torch.round(flow * 4)
+    if not torch.equal(q, flow * 4) or q.abs().max() > 32767:
+        raise _lib.ArsegError("resize_flow expects quarter-pel motion vectors (int16/4) as the reference datasets provide")
+    return ops.mv_resize(q.to(torch.int16), Hp, Wp)
+
+
+def _downscale_hw(H, W, scale):
+    return int(H * scale), int(W * scale)
+
+
+class EvalConstRes(object):
+    """evaluation.py:90-144."""
+
+    def __init__(self, scale=0.5, ignore_label=255):
+        self.ignore_label = ignore_label
+        self.scale = scale
+
+    def __call__(self, net, dl, n_classes):
+        hist = None
+        for imgs, label, *_ in dl:
+            label = label.cuda()
+            imgs = imgs.cuda()
+            N, C, H, W = imgs.shape
+            h, w = _downscale_hw(H, W, self.scale)
+            if (h, w) != (H, W):
+                imgs = _resize_frames(imgs, h, w)
+            logits = net(imgs)[0]
+            _, hist = ops.argmax_confusion(logits, label, label.shape[-2], label.shape[-1], hist, self.ignore_label, want_pred=False)
+        return _miou(hist, n_classes)
+
+
+def _resize_frames(imgs, h, w):
+    """F.interpolate(imgs, (h,w), bilinear, align_corners=True) on NCHW frames (evaluation.py:115-117)."""
+    return ops.resize_nchw(imgs, h, w, _lib.BILINEAR, True)
+
+
+def _miou(hist, n_classes):
+    hist = hist.float()
+    if dist.is_available() and dist.is_initialized():
+        dist.all_reduce(hist, dist.ReduceOp.SUM)                     # evaluation.py:134-135
+    ious = hist.diag() / (hist.sum(dim=0) + hist.sum(dim=1) - hist.diag())
+    return ious.mean().item()
+
+
+class EvalAlterRes(object):
+    """evaluation.py:148-215: keyframe through the HR net, non-keyframe through the LR net + CReFF."""
+
+    def __init__(self, scale=0.5, ignore_label=255):
+        self.ignore_label = ignore_label
+        self.scale = scale
+
+    def __call__(self, highres_net, net, dl, n_classes):
+        hist = None
+        lr_net = _unwrap(net)
+        for imgs, label, _, ref_imgs, flow in dl:
+            label = label.cuda()
+            imgs = imgs.cuda()
+            flow = flow.cuda()
+            highres_ref_p = highres_net(ref_imgs.cuda())[-1]                                  # :173-174
+            flow = resize_flow(flow, highres_ref_p.shape[-2], highres_ref_p.shape[-1])       # :177-180
+            highres_ref_p = warpFeature(highres_ref_p, flow)                                 # :183
+            N, C, H, W = imgs.shape
+            h, w = _downscale_hw(H, W, self.scale)
+            imgs = _resize_frames(imgs, h, w)                                                # :186-188
+            out_p = lr_net.forward_phase1(imgs)[-1]                                          # :190-191
+            out, _ = lr_net.forward_phase2(out_p, highres_ref_p)                             # :193
+            _, hist = ops.argmax_confusion(out, label, label.shape[-2], label.shape[-1], hist, self.ignore_label, want_pred=False)
+        return _miou(hist, n_classes)
+
+
+def alter_res_step_fast(lr_net, ref_p_nhwc, img, mv_q, scale=0.5):
+    """One non-keyframe on the kernel-native layouts.
+
+    ref_p_nhwc: keyframe feature, NHWC [N,Hp,Wp,C] (unwarped); img: NCHW frame; mv_q: int16 quarter-pel [N,H,W,2].
+    Returns (logits NCHW, p in C8 layout).  Same arithmetic as EvalAlterRes' loop body; the frame downscale is fused
+    into the NHWC4 ingest, the MV resize into the warp, and everything after the backbone into one CReFF kernel.
+    """
+    lr_net = _unwrap(lr_net)
+    N, C, H, W = img.shape
+    h, w = _downscale_hw(H, W, scale)
+    ref_c8 = ops.warp_mvq(ref_p_nhwc, mv_q, _lib.C8)                  # a2 + a1
+    feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(img, h, w))[-1]     # a3 + phase 1
+    return lr_net.phase2_c8(feat, ref_c8)                             # CReFF + head

@@ -1,0 +1,4 @@
+"""Mirrors of the reference's model package for the LR-branch inference hot path."""
+from .attention import MyAttention, f_similar, f_weighting  # noqa: F401
+from .pspnet import PSPNet, PSPNetWithFuse  # noqa: F401
+from .bisenet import BiSeNetV1, BiSeNetV1WithFuse  # noqa: F401

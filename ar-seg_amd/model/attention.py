@@ -1,0 +1,86 @@
+"""CReFF fusion module -- mirror of the reference's ``model/attention.py`` (hot-path part only).
+
+``MyAttention`` (model/attention.py:157-229) is the only variant the reference's evaluation ever
+constructs (model/pspnet.py:135-136, model/bisenet.py:500-501); the 17 ablation variants are out of
+scope.  ``f_similar`` / ``f_weighting`` (model/attention.py:13-53) keep their names and call the
+stand-alone HIP kernels; their backward passes (training) are not part of this path and raise.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from .. import _lib, ops, packing
+from ._common import HipModule
+
+
+class similarFunction(Function):
+    """model/attention.py:13-30 (forward only)."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_loc, kH, kW):
+        return ops.local_similar(x_ori, x_loc, kH, kW)
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        raise NotImplementedError("localAttention backward (training) is outside the LR-branch inference hot path")
+
+
+class weightingFunction(Function):
+    """model/attention.py:33-50 (forward only)."""
+
+    @staticmethod
+    def forward(ctx, x_ori, x_weight, kH, kW):
+        return ops.local_weighting(x_ori, x_weight, kH, kW)
+
+    @staticmethod
+    def backward(ctx, grad_outputs):
+        raise NotImplementedError("localAttention backward (training) is outside the LR-branch inference hot path")
+
+
+f_similar = similarFunction.apply
+f_weighting = weightingFunction.apply
+
+
+class MyAttention(HipModule):
+    """model/attention.py:157-229.  Note the reference's argument order ``(feat_dim, kW, kH)``."""
+
+    def __init__(self, feat_dim, kW, kH):
+        super().__init__()
+        self.lr_query_conv = nn.Conv2d(feat_dim, feat_dim, kernel_size=3, padding=1, groups=feat_dim)
+        self.hr_key_conv = nn.Conv2d(feat_dim, feat_dim, kernel_size=3, padding=1, groups=feat_dim)
+        self.hr_value_conv = nn.Conv2d(feat_dim, feat_dim, kernel_size=3, padding=1, groups=feat_dim)
+        self.softmax = nn.Softmax(dim=3)
+        self.kW = kW
+        self.kH = kH
+        self.init_weight()
+
+    def init_weight(self):
+        for ly in self.children():
+            if isinstance(ly, nn.Conv2d):
+                nn.init.kaiming_normal_(ly.weight, a=1)
+                if ly.bias is not None:
+                    nn.init.constant_(ly.bias, 0)
+
+    def _pack(self, device):
+        return packing.PackedAttention(self, device)
+
+    def fuse_c8(self, hr_c8, lr_nhwc, head=None, log_softmax=False):
+        """Kernel-layout entry: warped HR feature in C8, LR feature NHWC -> (p C8, logits NCHW | None)."""
+        return ops.creff(hr_c8, lr_nhwc, self.packed(), head, log_softmax, self.kH, self.kW)
+
+    def forward(self, hr_feat, lr_feat):
+        """hr_feat [N,C,H,W], lr_feat [N,C,h,w] (logical NCHW, any strides) -> [N,C,H,W]."""
+        hr_c8 = ops.to_c8(ops.to_nhwc(hr_feat), _lib.NHWC) if ops.is_nhwc_view(hr_feat) else ops.to_c8(hr_feat, _lib.NCHW)
+        p_c8, _ = self.fuse_c8(hr_c8, ops.to_nhwc(lr_feat))
+        return ops.as_nchw(ops.from_c8(p_c8, _lib.NHWC))
+
+    def get_params(self):
+        wd_params, nowd_params = [], []
+        for _, module in self.named_modules():
+            if isinstance(module, (nn.Linear, nn.Conv2d)):
+                wd_params.append(module.weight)
+                if module.bias is not None:
+                    nowd_params.append(module.bias)
+        return wd_params, nowd_params

@@ -1,0 +1,187 @@
+"""CamVid PSPNet-18 -- mirror of the reference's ``model/pspnet.py:14-231`` on libarseg_hip.so.
+
+Same class names, constructor keywords, ``forward`` / ``forward_phase1`` / ``forward_phase2``
+signatures and ``state_dict`` keys.  Tensors at the interface are logical NCHW; outputs produced
+here are physically NHWC (``torch.channels_last`` strides), which every entry point also accepts,
+so ``ref_p`` flows HR net -> warpFeature -> forward_phase2 without layout copies.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from .. import _lib, ops
+from ..packing import PackedConv, PackedHead
+from . import extractors
+from ._common import HipModule
+from .attention import MyAttention
+
+
+class PSPModule(HipModule):
+    """model/pspnet.py:14-31."""
+
+    def __init__(self, features, out_features=1024, sizes=(1, 2, 3, 6)):
+        super().__init__()
+        self.stages = nn.ModuleList([self._make_stage(features, size) for size in sizes])
+        self.bottleneck = nn.Conv2d(features * (len(sizes) + 1), out_features, kernel_size=1)
+        self.relu = nn.ReLU()
+        self.sizes = tuple(sizes)
+        self.features = features
+
+    def _make_stage(self, features, size):
+        prior = nn.AdaptiveAvgPool2d(output_size=(size, size))
+        conv = nn.Conv2d(features, features, kernel_size=1, bias=False)
+        return nn.Sequential(prior, conv)
+
+    def _pack(self, device):
+        return {"stages": [PackedConv.from_modules(st[1], device=device) for st in self.stages],
+                "bottleneck": PackedConv.from_modules(self.bottleneck, None, _lib.ACT_RELU, device=device)}
+
+    def alloc_cat(self, N, h, w, device):
+        """The 2560-channel concat buffer; the backbone writes its output straight into the last slice."""
+        C = self.features
+        cat = torch.empty((N, h, w, C * (len(self.sizes) + 1)), dtype=torch.float32, device=device)
+        return cat, cat[..., C * len(self.sizes):]
+
+    def forward_nhwc(self, cat):
+        pk = self.packed()
+        N, h, w, _ = cat.shape
+        C = self.features
+        feats = cat[..., C * len(self.sizes):]
+        for i, s in enumerate(self.sizes):
+            pooled = ops.adaptive_avgpool(feats, s, s)
+            prior = ops.conv2d(pooled, pk["stages"][i])
+            ops.resize_nhwc(prior, h, w, _lib.BILINEAR, False, out=cat[..., i * C:(i + 1) * C])     # F.upsample default
+        return ops.conv2d(cat, pk["bottleneck"])
+
+
+class PSPUpsample(HipModule):
+    """model/pspnet.py:34-46."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = nn.Sequential(nn.Conv2d(in_channels, out_channels, 3, padding=1), nn.BatchNorm2d(out_channels), nn.PReLU())
+
+    def _pack(self, device):
+        return PackedConv.from_modules(self.conv[0], self.conv[1], _lib.ACT_PRELU, float(self.conv[2].weight.item()), device=device)
+
+    def forward_nhwc(self, x):
+        N, h, w, C = x.shape
+        up = ops.resize_nhwc(x, 2 * h, 2 * w, _lib.BILINEAR, False)
+        return ops.conv2d(up, self.packed())
+
+
+class _PSPBase(HipModule):
+    """Everything PSPNet and PSPNetWithFuse share (the reference duplicates the code)."""
+
+    def _build(self, input_channel, n_classes, sizes, psp_size, deep_features_size, backend, pretrained):
+        self.feats = getattr(extractors, backend)(pretrained, input_channel=input_channel)
+        self.psp = PSPModule(psp_size, 1024, sizes)
+        self.drop_1 = nn.Dropout2d(p=0.3)
+        self.up_1 = PSPUpsample(1024, 256)
+        self.up_2 = PSPUpsample(256, 64)
+        self.up_3 = PSPUpsample(64, 64)
+        self.drop_2 = nn.Dropout2d(p=0.15)
+        self.final_conv = nn.Conv2d(64, n_classes, kernel_size=1)
+        self.final_logsoftmax = nn.LogSoftmax()
+        self.classifier = nn.Sequential(nn.Linear(deep_features_size, 256), nn.ReLU(), nn.Linear(256, n_classes))
+
+    def _pack(self, device):
+        return {"head": PackedHead(self.final_conv, device),
+                "cls0": PackedConv.from_modules(self.classifier[0], None, _lib.ACT_RELU, device=device),
+                "cls2": PackedConv.from_modules(self.classifier[2], None, _lib.ACT_NONE, device=device)}
+
+    def _trunk_nhwc(self, x):
+        """NCHW frame -> (aux logits [N,n_cls], p NHWC [N,H',W',64])."""
+        N, C, H, W = x.shape
+        return self.phase1_nhwc4(ops.frame_to_nhwc4(x, H, W))
+
+    def phase1_nhwc4(self, x4):
+        """The backbone on an NHWC4 frame (pspnet.py:198-217): -> (aux logits [N,n_cls], p NHWC)."""
+        N, H, W, _ = x4.shape
+        h8, w8 = _stride8(H), _stride8(W)
+        cat, f_slot = self.psp.alloc_cat(N, h8, w8, x4.device)
+        _, class_f = self.feats.forward_nhwc(x4, out_x=f_slot)
+        p = self.psp.forward_nhwc(cat)          # drop_1 / drop_2: identity in eval
+        p = self.up_1.forward_nhwc(p)
+        p = self.up_2.forward_nhwc(p)
+        p = self.up_3.forward_nhwc(p)
+        pk = self.packed()
+        aux = ops.global_reduce(class_f, _lib.REDUCE_MAX)
+        aux = ops.conv2d(ops.conv2d(aux, pk["cls0"]), pk["cls2"])
+        return aux.reshape(N, -1), p
+
+    def _final(self, p_nhwc, H, W):
+        """final_conv -> interpolate(align_corners=True) to (H,W) -> LogSoftmax (pspnet.py:96-98).  The 1x1 conv and
+        the bilinear resize are both linear and commute, so an (uncommon) size mismatch is handled by resizing p."""
+        if p_nhwc.shape[1] != H or p_nhwc.shape[2] != W:
+            p_nhwc = ops.resize_nhwc(p_nhwc, H, W, _lib.BILINEAR, True)
+        hd = self.packed()["head"]
+        return ops.head(p_nhwc, hd.wf, hd.bf, log_softmax=True)
+
+    def _forward_normal(self, x):
+        self._check_inference()
+        N, C, H, W = x.shape
+        aux, p = self._trunk_nhwc(x)
+        return self._final(p, H, W), aux, ops.as_nchw(p)
+
+
+def _stride8(n):
+    n = (n - 1) // 2 + 1      # conv 7x7 s2 p3
+    n = (n - 1) // 2 + 1      # maxpool 3x3 s2 p1
+    return (n - 1) // 2 + 1   # layer2 stride 2
+
+
+class PSPNet(_PSPBase):
+    """model/pspnet.py:49-100 (the HR / keyframe branch)."""
+
+    def __init__(self, input_channel=3, n_classes=18, sizes=(1, 2, 3, 6), psp_size=2048, deep_features_size=1024,
+                 backend='resnet34', pretrained=True):
+        super().__init__()
+        self._build(input_channel, n_classes, sizes, psp_size, deep_features_size, backend, pretrained)
+
+    def forward(self, x):
+        return self._forward_normal(x)
+
+
+class PSPNetWithFuse(_PSPBase):
+    """model/pspnet.py:103-231 (the LR branch with CReFF on the 64-channel full-resolution feature)."""
+
+    def __init__(self, input_channel=3, n_classes=18, sizes=(1, 2, 3, 6), psp_size=2048, deep_features_size=1024,
+                 backend='resnet34', pretrained=True, attention_type='local', atten_k=7):
+        super().__init__()
+        self._build(input_channel, n_classes, sizes, psp_size, deep_features_size, backend, pretrained)
+        self.middle_dim = 64
+        self.attention_type = attention_type
+        if attention_type != 'local':
+            raise NotImplementedError("only attention_type='local' (MyAttention) is on the hot path; the reference's "
+                                      "evaluation never constructs the ablation variants")
+        self.fuse_attention = MyAttention(self.middle_dim, kH=atten_k, kW=atten_k)
+
+    def forward(self, x, mode='normal', ref_p=None):
+        if mode == 'normal':
+            return self._forward_normal(x)
+        if mode == 'merge':
+            out_cls, out_p = self.forward_phase1(x)
+            out, out_p = self.forward_phase2(out_p, ref_p)
+            return out, out_cls, out_p
+        raise ValueError(mode)
+
+    def forward_phase1(self, x):
+        self._check_inference()
+        aux, p = self._trunk_nhwc(x)
+        return aux, ops.as_nchw(p)
+
+    def phase2_c8(self, p_nhwc, ref_c8, want_p=True):
+        """Kernel-layout phase 2 (fast path): LR feature NHWC + warped HR feature C8 -> (log-probs NCHW, p C8)."""
+        hd = self.packed()["head"]
+        p_c8, out = self.fuse_attention.fuse_c8(ref_c8, p_nhwc, head=(hd.wf, hd.bf), log_softmax=True)
+        return out, p_c8
+
+    def forward_phase2(self, p, ref_p):
+        self._check_inference()
+        N, C, H, W = ref_p.shape
+        ref_c8 = ops.to_c8(ops.to_nhwc(ref_p), _lib.NHWC) if ops.is_nhwc_view(ref_p) else ops.to_c8(ref_p, _lib.NCHW)
+        out, p_c8 = self.phase2_c8(ops.to_nhwc(p), ref_c8)
+        # F.interpolate(out, (H,W), align_corners=True) (pspnet.py:227) is the identity: out already is H x W
+        return out, ops.as_nchw(ops.from_c8(p_c8, _lib.NHWC))

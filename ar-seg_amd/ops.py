@@ -1,0 +1,366 @@
+"""Tensor-level wrappers over the C ABI (include/arseg_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every computation is a call into
+libarseg_hip.so.  All functions raise if a tensor is not a float32 CUDA(HIP) tensor -- there is no
+CPU or PyTorch fallback.
+
+Internal activation layout is NHWC: tensors of shape ``[N, H, W, C]`` (C contiguous).  The helpers
+``to_nhwc`` / ``to_nchw`` convert at the API boundary (the reference's interface is NCHW).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(*tensors, dtype=torch.float32):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ArsegError("arseg_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if dtype is not None and t.dtype != dtype:
+            raise _lib.ArsegError(f"expected {dtype}, got {t.dtype}")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+# ----------------------------------------------------------------------------------------------
+# workspace (caller-owned, as the ABI requires): one growing buffer per device
+# ----------------------------------------------------------------------------------------------
+_workspaces = {}
+
+
+def workspace(nbytes: int, device) -> torch.Tensor:
+    key = torch.device(device).index or 0
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+# ----------------------------------------------------------------------------------------------
+# layout helpers
+# ----------------------------------------------------------------------------------------------
+def is_nhwc_view(x: torch.Tensor) -> bool:
+    """True if logical-NCHW ``x`` is physically NHWC-contiguous (channels_last or a permuted NHWC tensor)."""
+    N, C, H, W = x.shape
+    return x.stride() == (H * W * C, 1, W * C, C)
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor -> physical NHWC tensor [N,H,W,C] (zero-copy when already channels_last)."""
+    _need_gpu(x)
+    N, C, H, W = x.shape
+    if is_nhwc_view(x):
+        return x.permute(0, 2, 3, 1)
+    x = x.contiguous()
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_nchw_to_nhwc_fwd(_ptr(x), _ptr(out), N, C, H * W, C, _stream()), "nchw_to_nhwc")
+    return out
+
+
+def as_nchw(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """Physical NHWC [N,H,W,C] -> logical NCHW view (channels_last strides, no copy)."""
+    return x_nhwc.permute(0, 3, 1, 2)
+
+
+def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x_nhwc)
+    N, H, W, C = x_nhwc.shape
+    out = torch.empty((N, C, H, W), dtype=torch.float32, device=x_nhwc.device)
+    check(_lib.load().arseg_nhwc_to_nchw_fwd(_ptr(x_nhwc), C, _ptr(out), N, C, H * W, _stream()), "nhwc_to_nchw")
+    return out
+
+
+def to_c8(x: torch.Tensor, layout: int) -> torch.Tensor:
+    """NCHW-contiguous [N,C,H,W] or NHWC [N,H,W,C] -> channel-blocked [N,C/8,H,W,8]."""
+    _need_gpu(x)
+    if layout == _lib.NCHW:
+        N, C, H, W = x.shape
+        x = x.contiguous()
+        ld = 0
+    else:
+        N, H, W, C = x.shape
+        x = x.contiguous()
+        ld = C
+    out = torch.empty((N, C // 8, H, W, 8), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_to_c8_fwd(_ptr(x), layout, ld, _ptr(out), N, C, H * W, _stream()), "to_c8")
+    return out
+
+
+def from_c8(x: torch.Tensor, layout: int) -> torch.Tensor:
+    _need_gpu(x)
+    N, CB, H, W, _ = x.shape
+    C = CB * 8
+    shape = (N, C, H, W) if layout == _lib.NCHW else (N, H, W, C)
+    out = torch.empty(shape, dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_from_c8_fwd(_ptr(x), _ptr(out), layout, C, N, C, H * W, _stream()), "from_c8")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# localAttention pair
+# ----------------------------------------------------------------------------------------------
+def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
+    _need_gpu(q, k)
+    q, k = q.contiguous(), k.contiguous()
+    N, C, H, W = q.shape
+    out = torch.empty((N, H, W, kH * kW), dtype=torch.float32, device=q.device)
+    check(_lib.load().arseg_local_similar_fwd(_ptr(q), _ptr(k), _ptr(out), N, C, H, W, kH, kW, _stream()), "local_similar")
+    return out
+
+
+def local_weighting(v: torch.Tensor, w: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
+    _need_gpu(v, w)
+    v, w = v.contiguous(), w.contiguous()
+    N, C, H, W = v.shape
+    out = torch.empty_like(v)
+    check(_lib.load().arseg_local_weighting_fwd(_ptr(v), _ptr(w), _ptr(out), N, C, H, W, kH, kW, _stream()), "local_weighting")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# warp / motion vectors
+# ----------------------------------------------------------------------------------------------
+def warp(feature: torch.Tensor, flow: torch.Tensor, layout: int, out_layout: Optional[int] = None) -> torch.Tensor:
+    """feature NCHW-contiguous [N,C,H,W] (layout=NCHW) or NHWC [N,H,W,C]; flow [N,H,W,2] f32/f64."""
+    _need_gpu(feature)
+    _need_gpu(flow, dtype=None)
+    if flow.dtype not in (torch.float32, torch.float64):
+        raise _lib.ArsegError(f"flow must be float32 or float64, got {flow.dtype}")
+    feature, flow = feature.contiguous(), flow.contiguous()
+    if layout == _lib.NCHW:
+        N, C, H, W = feature.shape
+    else:
+        N, H, W, C = feature.shape
+    out_layout = layout if out_layout is None else out_layout
+    if out_layout == _lib.C8:
+        out = torch.empty((N, C // 8, H, W, 8), dtype=torch.float32, device=feature.device)
+    else:
+        out = torch.empty_like(feature)
+    fd = _lib.FLOW_F64 if flow.dtype == torch.float64 else _lib.FLOW_F32
+    check(_lib.load().arseg_warp_fwd(_ptr(feature), _ptr(flow), fd, _ptr(out), N, C, H, W, layout, out_layout, _stream()), "warp")
+    return out
+
+
+def mv_resize(mv_q: torch.Tensor, Hp: int, Wp: int) -> torch.Tensor:
+    """int16 quarter-pel [N,H,W,2] -> float64 [N,Hp,Wp,2] (evaluation.py:176-180)."""
+    _need_gpu(mv_q, dtype=torch.int16)
+    mv_q = mv_q.contiguous()
+    N, H, W, _ = mv_q.shape
+    out = torch.empty((N, Hp, Wp, 2), dtype=torch.float64, device=mv_q.device)
+    check(_lib.load().arseg_mv_resize_fwd(_ptr(mv_q), _ptr(out), N, H, W, Hp, Wp, _stream()), "mv_resize")
+    return out
+
+
+def warp_mvq(feature_nhwc: torch.Tensor, mv_q: torch.Tensor, out_layout: int = _lib.C8) -> torch.Tensor:
+    """MV resize + warp fused: NHWC feature [N,Hp,Wp,C], int16 quarter-pel MVs [N,H,W,2] at frame resolution."""
+    _need_gpu(feature_nhwc)
+    _need_gpu(mv_q, dtype=torch.int16)
+    feature_nhwc, mv_q = feature_nhwc.contiguous(), mv_q.contiguous()
+    N, Hp, Wp, C = feature_nhwc.shape
+    _, H, W, _ = mv_q.shape
+    shape = (N, C // 8, Hp, Wp, 8) if out_layout == _lib.C8 else (N, Hp, Wp, C)
+    out = torch.empty(shape, dtype=torch.float32, device=feature_nhwc.device)
+    check(_lib.load().arseg_warp_mvq_fwd(_ptr(feature_nhwc), _ptr(mv_q), _ptr(out), N, C, Hp, Wp, H, W, out_layout, _stream()),
+          "warp_mvq")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# CReFF
+# ----------------------------------------------------------------------------------------------
+def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softmax: bool = False, kH: int = 7, kW: int = 7
+          ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """attn: packing.PackedAttention; head: None or (wf [n_cls,C], bf [n_cls]) device tensors.
+    Returns (p in C8 layout, logits NCHW or None)."""
+    _need_gpu(hr_c8, lr_nhwc)
+    hr_c8, lr_nhwc = hr_c8.contiguous(), lr_nhwc.contiguous()
+    N, CB, Hp, Wp, _ = hr_c8.shape
+    C = CB * 8
+    _, hp, wp, C2 = lr_nhwc.shape
+    if C2 != C:
+        raise _lib.ArsegError(f"channel mismatch: hr has {C}, lr has {C2}")
+    p_out = torch.empty_like(hr_c8)
+    logits, wf, bf, n_cls = None, None, None, 0
+    if head is not None:
+        wf, bf = head
+        n_cls = wf.shape[0]
+        logits = torch.empty((N, n_cls, Hp, Wp), dtype=torch.float32, device=hr_c8.device)
+    check(_lib.load().arseg_creff_fwd(_ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
+                                      _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
+                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, _stream()), "creff")
+    return p_out, logits
+
+
+# ----------------------------------------------------------------------------------------------
+# conv engine
+# ----------------------------------------------------------------------------------------------
+def _nhwc_ld(t: torch.Tensor) -> int:
+    """Channel stride (floats per pixel) of an NHWC tensor that may be a channel slice of a wider NHWC buffer."""
+    N, H, W, C = t.shape
+    sN, sH, sW, sC = t.stride()
+    bad = C > 1 and sC != 1
+    if W > 1:
+        ld = sW
+    elif H > 1:
+        ld = sH
+    elif N > 1:
+        ld = sN
+    else:
+        ld = max(sW, C)
+    bad = bad or ld < C or (H > 1 and sH != W * ld) or (N > 1 and sN != H * W * ld)
+    if bad:
+        raise _lib.ArsegError(f"tensor is not an NHWC (slice) view: shape {tuple(t.shape)} strides {t.stride()}")
+    return ld
+
+
+def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           tile_cfg: int = 0, split_k: int = 0) -> torch.Tensor:
+    """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view."""
+    _need_gpu(x, residual, out)
+    N, H, W, Cin = x.shape
+    if Cin != pc.cin_pad:
+        raise _lib.ArsegError(f"conv expects {pc.cin_pad} input channels (padded), got {Cin}")
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, _nhwc_ld(x)
+    d.Cout = pc.cout
+    d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
+    d.act, d.prelu_slope = pc.act, pc.slope
+    d.tile_cfg, d.split_k = tile_cfg, split_k
+    d.out_ld, d.res_ld = pc.cout, pc.cout     # provisional, for the shape query
+    lib = _lib.load()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    check(lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv_out_hw")
+    Ho, Wo = ho.value, wo.value
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pc.cout), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (N, Ho, Wo, pc.cout):
+        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(N, Ho, Wo, pc.cout)}")
+    d.out_ld = _nhwc_ld(out)
+    if residual is not None:
+        if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
+            raise _lib.ArsegError("residual shape mismatch")
+        d.res_ld = _nhwc_ld(residual)
+    nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = workspace(nbytes, x.device) if nbytes else None
+    check(lib.arseg_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out),
+                               _ptr(ws), nbytes, _stream()), "conv2d")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# small layers
+# ----------------------------------------------------------------------------------------------
+def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    _need_gpu(x)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_maxpool3x3s2_fwd(_ptr(x), _ptr(out), N, H, W, C, _stream()), "maxpool")
+    return out
+
+
+def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
+    _need_gpu(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_adaptive_avgpool_fwd(_ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, oh, ow, _stream()), "adaptive_avgpool")
+    return out
+
+
+def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
+    """NHWC -> [N,1,1,C] mean or max over (H,W)."""
+    _need_gpu(x)
+    N, H, W, C = x.shape
+    out = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_global_reduce_fwd(_ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, op, _stream()), "global_reduce")
+    return out
+
+
+def resize_nhwc(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_gpu(x, out)
+    N, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((N, Hout, Wout, C), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_resize_fwd(_ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NHWC,
+                                       _nhwc_ld(x), _nhwc_ld(out), _stream()), "resize_nhwc")
+    return out
+
+
+def resize_nchw(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners: bool) -> torch.Tensor:
+    _need_gpu(x)
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    out = torch.empty((N, C, Hout, Wout), dtype=torch.float32, device=x.device)
+    check(_lib.load().arseg_resize_fwd(_ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NCHW, 0, 0,
+                                       _stream()), "resize_nchw")
+    return out
+
+
+def scale_add(x: torch.Tensor, scale: torch.Tensor, add_full: Optional[torch.Tensor] = None, add_vec: Optional[torch.Tensor] = None
+              ) -> torch.Tensor:
+    """out = x * scale[n,c] (+ add_full[n,h,w,c]) (+ add_vec[n,c]); x NHWC contiguous, scale/add_vec [N,1,1,C]."""
+    _need_gpu(x, scale, add_full, add_vec)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    out = torch.empty_like(x)
+    if add_full is not None:
+        add_full = add_full.contiguous()
+    check(_lib.load().arseg_scale_add_fwd(_ptr(x), _ptr(scale.contiguous()), _ptr(add_full),
+                                          _ptr(None if add_vec is None else add_vec.contiguous()), _ptr(out), N, H * W, C, _stream()),
+          "scale_add")
+    return out
+
+
+def head(p_nhwc: torch.Tensor, wf: torch.Tensor, bf: torch.Tensor, log_softmax: bool) -> torch.Tensor:
+    """1x1 classifier on an NHWC feature -> NCHW logits (optionally LogSoftmax over classes)."""
+    _need_gpu(p_nhwc, wf, bf)
+    N, H, W, C = p_nhwc.shape
+    n_cls = wf.shape[0]
+    out = torch.empty((N, n_cls, H, W), dtype=torch.float32, device=p_nhwc.device)
+    check(_lib.load().arseg_head_fwd(_ptr(p_nhwc), _nhwc_ld(p_nhwc), _ptr(wf), _ptr(bf), _ptr(out), N, H * W, C, n_cls,
+                                     1 if log_softmax else 0, _stream()), "head")
+    return out
+
+
+def frame_to_nhwc4(img: torch.Tensor, h: int, w: int) -> torch.Tensor:
+    """NCHW RGB frame -> NHWC4, bilinear(align_corners=True) resized to (h,w) (evaluation.py:186-188)."""
+    _need_gpu(img)
+    img = img.contiguous()
+    N, C, H, W = img.shape
+    if C != 3:
+        raise _lib.ArsegError("frame_to_nhwc4 expects 3 input channels")
+    out = torch.empty((N, h, w, 4), dtype=torch.float32, device=img.device)
+    check(_lib.load().arseg_frame_to_nhwc4_fwd(_ptr(img), _ptr(out), N, H, W, h, w, _stream()), "frame_to_nhwc4")
+    return out
+
+
+def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int, W: int, hist: Optional[torch.Tensor] = None,
+                     ignore_label: int = 255, want_pred: bool = True):
+    """Evaluator tail (evaluation.py:201-209): returns (pred int32 [N,H,W] or None, hist int64 [n_cls,n_cls] or None)."""
+    _need_gpu(logits)
+    logits = logits.contiguous()
+    N, n_cls, h, w = logits.shape
+    pred = torch.empty((N, H, W), dtype=torch.int32, device=logits.device) if want_pred else None
+    if label is not None:
+        _need_gpu(label, dtype=torch.int64)
+        label = label.contiguous()
+        if hist is None:
+            hist = torch.zeros((n_cls, n_cls), dtype=torch.int64, device=logits.device)
+    check(_lib.load().arseg_argmax_confusion_fwd(_ptr(logits), _ptr(label), _ptr(pred), _ptr(hist if label is not None else None), N,
+                                                 n_cls, h, w, H, W, ignore_label, _stream()), "argmax_confusion")
+    return pred, hist

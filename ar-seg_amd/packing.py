@@ -1,0 +1,95 @@
+"""Weight packer: reference ``state_dict`` tensors -> the layouts the HIP kernels consume.
+
+* conv / linear weights OIHW -> ``[Cout][Kpad]`` with k = (r*S+s)*Cin_pad + ci (arseg_pack_conv_weight_host)
+* BatchNorm (eval) folded into a per-channel scale/bias together with the conv bias (arseg_fold_bn_host)
+* depthwise 3x3 weights of CReFF ``[C][1][3][3]`` -> ``[9][C]`` (arseg_pack_dw3x3_host)
+
+The arithmetic is done by the host-side entry points of libarseg_hip.so on CPU buffers; this module
+only moves the results to the device.  Done once per model (first forward / after load_state_dict).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+def _np(t) -> np.ndarray:
+    return np.ascontiguousarray(t.detach().cpu().numpy() if torch.is_tensor(t) else t, dtype=np.float32)
+
+
+def _hp(a: Optional[np.ndarray]):
+    return ctypes.c_void_p(0 if a is None else a.ctypes.data)
+
+
+class PackedConv:
+    """A conv (or linear) layer with its folded epilogue, resident on ``device``."""
+
+    def __init__(self, weight, conv_bias=None, bn=None, stride=1, pad=0, dil=1, act=_lib.ACT_NONE, slope=0.0, device="cuda",
+                 bn_eps=1e-5):
+        lib = _lib.load()
+        w = _np(weight)
+        if w.ndim == 2:                      # nn.Linear == 1x1 conv on a 1x1 image
+            w = w[:, :, None, None]
+        cout, cin, R, S = w.shape
+        self.cout, self.cin, self.R, self.S = cout, cin, R, S
+        self.cin_pad = (cin + 3) // 4 * 4
+        self.stride, self.pad, self.dil, self.act, self.slope = int(stride), int(pad), int(dil), int(act), float(slope)
+        kpad = lib.arseg_packed_k(self.cin_pad, R, S)
+        packed = np.empty((cout, kpad), dtype=np.float32)
+        check(lib.arseg_pack_conv_weight_host(_hp(w), cout, cin, R, S, self.cin_pad, _hp(packed)), "pack_conv_weight")
+        self.w = torch.from_numpy(packed).to(device)
+        cb = None if conv_bias is None else _np(conv_bias)
+        if bn is not None:
+            gamma, beta, mean, var = (_np(t) for t in bn)
+            scale = np.empty(cout, dtype=np.float32)
+            bias = np.empty(cout, dtype=np.float32)
+            check(lib.arseg_fold_bn_host(_hp(gamma), _hp(beta), _hp(mean), _hp(var), ctypes.c_float(bn_eps), _hp(cb), cout,
+                                         _hp(scale), _hp(bias)), "fold_bn")
+            self.scale = torch.from_numpy(scale).to(device)
+            self.bias = torch.from_numpy(bias).to(device)
+        else:
+            self.scale = None
+            self.bias = None if cb is None else torch.from_numpy(cb).to(device)
+
+    @staticmethod
+    def from_modules(conv, bn=None, act=_lib.ACT_NONE, slope=0.0, device="cuda"):
+        """conv: nn.Conv2d or nn.Linear; bn: nn.BatchNorm2d or None."""
+        is_conv = conv.weight.dim() == 4
+        return PackedConv(conv.weight, conv.bias,
+                          None if bn is None else (bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                          stride=conv.stride[0] if is_conv else 1, pad=conv.padding[0] if is_conv else 0,
+                          dil=conv.dilation[0] if is_conv else 1, act=act, slope=slope, device=device,
+                          bn_eps=1e-5 if bn is None else bn.eps)
+
+
+class PackedAttention:
+    """The three depthwise 3x3 convs of MyAttention (model/attention.py:161-164), tap-major."""
+
+    def __init__(self, attn_module, device="cuda"):
+        lib = _lib.load()
+
+        def dw(conv):
+            w = _np(conv.weight)
+            C = w.shape[0]
+            out = np.empty((9, C), dtype=np.float32)
+            check(lib.arseg_pack_dw3x3_host(_hp(w), C, _hp(out)), "pack_dw3x3")
+            return torch.from_numpy(out).to(device), torch.from_numpy(_np(conv.bias)).to(device)
+
+        self.wq, self.bq = dw(attn_module.lr_query_conv)
+        self.wk, self.bk = dw(attn_module.hr_key_conv)
+        self.wv, self.bv = dw(attn_module.hr_value_conv)
+
+
+class PackedHead:
+    """final 1x1 classifier (model/pspnet.py:66, model/bisenet.py:211): wf [n_cls][C], bf [n_cls]."""
+
+    def __init__(self, conv, device="cuda"):
+        w = _np(conv.weight)
+        self.wf = torch.from_numpy(np.ascontiguousarray(w.reshape(w.shape[0], w.shape[1]))).to(device)
+        self.bf = torch.from_numpy(_np(conv.bias)).to(device)

@@ -1,0 +1,185 @@
+/*
+ * arseg_hip.h -- C ABI of libarseg_hip.so: the MI355X (gfx950) kernels of AR-Seg's LR-branch
+ * inference hot path.  This is the drop-in boundary: plain pointers and
+ * sizes, no torch / C++ types.  Each entry point cites the reference interface it replaces
+ * (paths relative to the AR-Seg repository).
+ *
+ * Conventions
+ *   - All data pointers are DEVICE pointers unless the name ends in `_host`.
+ *   - The caller owns every buffer (inputs, outputs, workspace).  Nothing is allocated here.
+ *   - Every function only ENQUEUES work on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and never synchronises the device.
+ *   - Return value: 0 = ok; < 0 = ARSEG_E* (argument / shape problem, nothing was launched);
+ *     > 0 = a hipError_t from the launch.  Nothing throws or aborts.
+ *   - "NHWC" tensors are [N][H][W][ld] floats with `ld >= C` the per-pixel channel stride, so a
+ *     channel slice of a wider tensor can be read or written in place (concat without copies).
+ *   - No hidden global state; the library is thread-compatible (one stream per caller thread).
+ */
+#ifndef ARSEG_HIP_H
+#define ARSEG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARSEG_ABI_VERSION 1
+
+enum arseg_status {
+    ARSEG_OK = 0,
+    ARSEG_EINVAL = -1,        /* null pointer, non-positive size, misaligned pointer / stride */
+    ARSEG_EUNSUPPORTED = -2,  /* shape outside what the kernels are built for (see each function) */
+    ARSEG_EWORKSPACE = -3     /* workspace too small; query the *_workspace_bytes function */
+};
+
+enum arseg_act { ARSEG_ACT_NONE = 0, ARSEG_ACT_RELU = 1, ARSEG_ACT_PRELU = 2, ARSEG_ACT_SIGMOID = 3 };
+enum arseg_layout { ARSEG_NCHW = 0, ARSEG_NHWC = 1, ARSEG_C8 = 2 /* [N][C/8][H][W][8], the CReFF kernel's layout */ };
+enum arseg_flow_dtype { ARSEG_FLOW_F32 = 0, ARSEG_FLOW_F64 = 1 };
+enum arseg_resize_mode { ARSEG_NEAREST = 0, ARSEG_BILINEAR = 1 };
+enum arseg_reduce_op { ARSEG_REDUCE_MEAN = 0, ARSEG_REDUCE_MAX = 1 };
+
+typedef void *arseg_stream_t; /* hipStream_t */
+
+int arseg_version(void);
+const char *arseg_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * The `localAttention` pair (third-party CUDA extension the reference imports at
+ * model/attention.py:7-11; call sites model/attention.py:18 and :38).
+ *   similar  : s[n,y,x,dy*kW+dx] = sum_c q[n,c,y,x] * k[n,c,y+dy-kH/2,x+dx-kW/2]   (0 outside)
+ *   weighting: o[n,c,y,x]        = sum_i v[n,c,y+dy_i-kH/2,x+dx_i-kW/2] * w[n,y,x,i] (0 outside)
+ * q,k,v,o: NCHW contiguous fp32; s,w: [N,H,W,kH*kW].  kH,kW odd, kH*kW <= 121.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_local_similar_fwd(const float *q, const float *k, float *s, int N, int C, int H, int W, int kH, int kW,
+                            arseg_stream_t stream);
+int arseg_local_weighting_fwd(const float *v, const float *w, float *o, int N, int C, int H, int W, int kH, int kW,
+                              arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * warpFeature(feature, flow)                                            evaluation.py:61-87
+ * feature: [N,C,H,W] in `layout` (NCHW or NHWC with ld == C); out: same layout, or C8 when
+ * out_layout == ARSEG_C8 (NHWC input only); flow: [N,H,W,2] (dx,dy) in feature pixels, fp32 or fp64.  Sampling = grid_sample(bilinear, zeros, align_corners=False) of the grid
+ * normalised with 2*g/(W-1)-1, reproduced operation by operation (fp64 grid -> fp32 cast).
+ * NHWC requires C % 4 == 0.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_warp_fwd(const float *feature, const void *flow, int flow_dtype, float *out, int N, int C, int H, int W,
+                   int layout, int out_layout, arseg_stream_t stream);
+
+/* Motion-vector resize block                                            evaluation.py:176-180
+ * mv_q: int16 quarter-pel [N,H,W,2] exactly as stored on disk (dataset/camvid.py:624-626,
+ * dataset/cityscapes.py:282-285); out: fp64 [N,Hp,Wp,2] = bilinear(align_corners=True) of
+ * (mv_q/4) * Hp/H (both components scaled by Hp/H as the reference does). */
+int arseg_mv_resize_fwd(const int16_t *mv_q, double *out, int N, int H, int W, int Hp, int Wp, arseg_stream_t stream);
+
+/* The two steps above fused (fast path): warp an NHWC feature straight from the int16 MV map;
+ * out_layout = ARSEG_NHWC or ARSEG_C8. */
+int arseg_warp_mvq_fwd(const float *feature, const int16_t *mv_q, float *out, int N, int C, int Hp, int Wp, int H,
+                       int W, int out_layout, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * CReFF: MyAttention.forward(hr_feat, lr_feat) [+ final 1x1 classifier]
+ *                                   model/attention.py:184-213; model/pspnet.py:219-231;
+ *                                   model/bisenet.py:565-575
+ * One fused kernel: bilinear(align_corners=True) upsample of lr, the three depthwise 3x3 convs
+ * (+bias), the kH x kW local QK^T with zero-score padding taps, softmax over all kH*kW taps,
+ * PV, residual add; optionally the 1x1 classifier (+ log-softmax over classes) on the result.
+ *   hr   : C8 [N,C/8,Hp,Wp,8]  (already warped; arseg_warp*_fwd can write it directly)
+ *   lr   : NHWC [N,hp,wp,C] (ld == C)
+ *   wq/wk/wv : depthwise weights packed [9][C] (tap-major), bq/bk/bv : [C]
+ *   p_out: C8 [N,C/8,Hp,Wp,8]   (channel-blocked so that the kernel's 8-channel chunks are contiguous)
+ *   logits: NCHW [N,n_cls,Hp,Wp] or NULL (then wf/bf are ignored); wf: [n_cls][C], bf: [n_cls];
+ *   log_softmax != 0 applies LogSoftmax over the class dimension (PSPNet head).
+ * Supported: C % 8 == 0, kH == kW in {3,5,7}, n_cls <= 32, N*C*Hp*Wp*4 < 2 GiB.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_creff_fwd(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
+                    const float *bk, const float *wv, const float *bv, float *p_out, const float *wf, const float *bf,
+                    int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH,
+                    int kW, arseg_stream_t stream);
+
+/* Layout changes to / from C8 at the API boundary (layout = ARSEG_NCHW or ARSEG_NHWC; ld = NHWC channel stride). */
+int arseg_to_c8_fwd(const float *in, int layout, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);
+int arseg_from_c8_fwd(const float *in, float *out, int layout, int out_ld, int N, int C, int HW, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * conv2d (+ folded BatchNorm / bias, + residual add, + activation) as an implicit GEMM on the
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces every nn.Conv2d/BatchNorm2d/ReLU/PReLU stack of
+ * model/extractors.py:35-66,108-158, model/pspnet.py:14-46 and model/bisenet.py:31-60,162-399.
+ *   out[n,oy,ox,co] = act( scale[co] * sum_{r,s,ci} in[n, oy*stride-pad+r*dil, ox*stride-pad+s*dil, ci]
+ *                                        * w[co][(r*S+s)*Cin+ci]  + bias[co] + residual[n,oy,ox,co] )
+ * in: NHWC (in_ld), Cin % 4 == 0 (pad RGB to 4), Cin a power of two unless R*S == 1.
+ * w_packed: [Cout][Kpad] from arseg_pack_conv_weight_host.  scale/bias: [Cout] or NULL (1 / 0).
+ * residual: NHWC (res_ld) or NULL.  tile_cfg / split_k: 0 = choose automatically.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct arseg_conv_desc {
+    int N, H, W, Cin, in_ld;
+    int Cout, out_ld, res_ld;
+    int R, S, stride, pad, dil;
+    int act;           /* enum arseg_act */
+    float prelu_slope; /* single shared slope (nn.PReLU() default, model/pspnet.py:40) */
+    int tile_cfg;      /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 */
+    int split_k;       /* 0 auto, >= 1 explicit */
+} arseg_conv_desc;
+
+int arseg_conv_out_hw(const arseg_conv_desc *d, int *Ho, int *Wo);
+size_t arseg_conv2d_workspace_bytes(const arseg_conv_desc *d);
+int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale,
+                     const float *bias, const float *residual, float *out, void *workspace, size_t workspace_bytes,
+                     arseg_stream_t stream);
+
+/* Host-side weight preparation (the "weight packer"; CPU pointers).
+ * arseg_packed_k: padded GEMM depth for a conv (multiple of 32).
+ * arseg_pack_conv_weight_host: OIHW [Cout][Cin][R][S] -> [Cout][Kpad], k = (r*S+s)*Cin_pad + ci, zero padded.
+ * arseg_fold_bn_host: scale = gamma/sqrt(var+eps), bias = beta + (conv_bias - mean)*scale  (conv_bias may be NULL).
+ * arseg_pack_dw3x3_host: depthwise [C][1][3][3] -> [9][C]. */
+int arseg_packed_k(int Cin_pad, int R, int S);
+int arseg_pack_conv_weight_host(const float *w_oihw, int Cout, int Cin, int R, int S, int Cin_pad, float *out_host);
+int arseg_fold_bn_host(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
+                       const float *conv_bias, int C, float *scale_out, float *bias_out);
+int arseg_pack_dw3x3_host(const float *w, int C, float *out_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * Small NHWC layers of the backbones.
+ * ------------------------------------------------------------------------------------------- */
+/* nn.MaxPool2d(3, stride 2, padding 1)             model/extractors.py:116, model/bisenet.py:77 */
+int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream);
+/* nn.AdaptiveAvgPool2d((oh,ow))                                            model/pspnet.py:23 */
+int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int oh, int ow,
+                               arseg_stream_t stream);
+/* torch.mean(x,(2,3)) / F.adaptive_max_pool2d(x,1): out [N][C]   model/bisenet.py:252,292,390; pspnet.py:94 */
+int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op,
+                            arseg_stream_t stream);
+/* F.interpolate / F.upsample / nn.Upsample: nearest or bilinear, align_corners on/off, either layout.
+ * NHWC: in_ld/out_ld channel strides (C % 4 == 0); NCHW: planes contiguous, ld arguments ignored.
+ * model/pspnet.py:29,45,97; model/bisenet.py:215,284,298,442; evaluation.py:117,188,201 */
+int arseg_resize_fwd(const float *in, float *out, int N, int C, int Hin, int Win, int Hout, int Wout, int mode,
+                     int align_corners, int layout, int in_ld, int out_ld, arseg_stream_t stream);
+/* out[n,y,x,c] = x[n,y,x,c] * scale[n,c] + (add_full ? add_full[n,y,x,c] : 0) + (add_vec ? add_vec[n,c] : 0)
+ * ARM: feat*atten (+avg)  model/bisenet.py:258,295;  FFM: feat*atten + feat  model/bisenet.py:397-398 */
+int arseg_scale_add_fwd(const float *x, const float *scale, const float *add_full, const float *add_vec, float *out,
+                        int N, int HW, int C, arseg_stream_t stream);
+/* final 1x1 classifier on an NHWC feature, NCHW logits out (+ optional LogSoftmax over classes)
+ * model/pspnet.py:66-67,96-98; model/bisenet.py:211,448 */
+int arseg_head_fwd(const float *p, int p_ld, const float *wf, const float *bf, float *logits, int N, int HW, int C,
+                   int n_cls, int log_softmax, arseg_stream_t stream);
+/* decoded frame NCHW [N,3,H,W] -> NHWC4 [N,h,w,4] (4th channel 0), bilinear align_corners=True when (h,w) != (H,W)
+ * evaluation.py:115-117,186-188 fused with the layout change the conv engine wants */
+int arseg_frame_to_nhwc4_fwd(const float *img, float *out, int N, int H, int W, int h, int w, arseg_stream_t stream);
+/* layout changes at the API boundary */
+int arseg_nchw_to_nhwc_fwd(const float *in, float *out, int N, int C, int HW, int out_ld, arseg_stream_t stream);
+int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Evaluator tail                                                       evaluation.py:201-213
+ * logits NCHW [N,n_cls,h,w] -> (bilinear align_corners=True to HxW) -> argmax -> pred int32 [N,H,W]
+ * and hist[label*n_cls+pred] += 1 for label != ignore_label (hist: int64 [n_cls*n_cls], accumulated).
+ * pred or hist/label may be NULL.  softmax before argmax is monotone and omitted.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_t *pred, int64_t *hist, int N,
+                               int n_cls, int h, int w, int H, int W, int ignore_label, arseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARSEG_HIP_H */

@@ -1,0 +1,383 @@
+"""GPU parity tests, op level: every entry point of libarseg_hip.so against the oracle on seeded inputs
+(the oracle -- oracle/cpu_ref.py, oracle/local_attn_ref.c, torch CPU functional ops -- is the checker only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import maxdiff, t
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from arseg_amd import _lib
+
+    _lib.load()          # the HIP library must be the thing under test: fail loudly if it is missing
+    return torch.device("cuda:0")
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
+
+
+# ---------------------------------------------------------------------------------------------- localAttention pair
+@pytest.mark.parametrize("N,C,H,W,kH,kW", [(1, 8, 10, 12, 7, 7), (2, 5, 9, 33, 5, 5), (1, 3, 4, 5, 7, 7), (1, 16, 17, 70, 3, 3),
+                                            (2, 6, 9, 8, 5, 7), (1, 64, 24, 40, 7, 7), (1, 1, 1, 1, 7, 7)])
+def test_local_pair(dev, N, C, H, W, kH, kW):
+    from arseg_amd import ops
+    from oracle import c_ref, cpu_ref
+
+    q, k = rnd(1, N, C, H, W), rnd(2, N, C, H, W)
+    w = torch.softmax(rnd(3, N, H, W, kH * kW), dim=3)
+    s = ops.local_similar(q.to(dev), k.to(dev), kH, kW).cpu()
+    o = ops.local_weighting(k.to(dev), w.to(dev), kH, kW).cpu()
+    assert maxdiff(s, cpu_ref.local_similar(q, k, kH, kW)) <= 1e-4
+    assert maxdiff(o, cpu_ref.local_weighting(k, w, kH, kW)) <= 1e-5
+    assert maxdiff(s, c_ref.local_similar(q.numpy(), k.numpy(), kH, kW)) <= 1e-4
+    assert maxdiff(o, c_ref.local_weighting(k.numpy(), w.numpy(), kH, kW)) <= 1e-5
+
+
+def test_local_pair_golden_and_shim(dev, golden):
+    import arseg_amd.localAttention as la
+    from arseg_amd.model import f_similar, f_weighting
+
+    g = golden("g3_pair")
+    kH, kW = int(g["kH"]), int(g["kW"])
+    v, w, q = (t(g[k]).to(dev) for k in ("v", "w", "q"))
+    assert maxdiff(la.weighting_forward(v, w, kH, kW), g["weighting_cpu"]) <= 1e-5      # reference's f_weighting_cpu
+    assert maxdiff(la.similar_forward(q, v, kH, kW), g["similar_shim"]) <= 1e-5
+    assert maxdiff(f_weighting(v, w, kH, kW), g["weighting_cpu"]) <= 1e-5
+    assert maxdiff(f_similar(q, v, kH, kW), g["similar_shim"]) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        la.similar_backward(q, v, kH, kW, True)
+
+
+# ---------------------------------------------------------------------------------------------- warp / MVs
+@pytest.mark.parametrize("seed", [0, 1])
+def test_warp_golden(dev, golden, seed):
+    from arseg_amd import evaluation as ev
+
+    g = golden(f"g1_warp_s{seed}")
+    feat = t(g["feat"]).to(dev)
+    for k in ("int", "frac", "f32"):
+        flow = t(g[f"flow_{k}"]).to(dev)
+        assert maxdiff(ev.warpFeature(feat, flow), g[f"out_{k}"]) <= 1e-5                       # NCHW kernel
+        cl = feat.contiguous(memory_format=torch.channels_last)
+        out = ev.warpFeature(cl, flow)                                                          # NHWC kernel
+        assert out.shape == feat.shape and maxdiff(out, g[f"out_{k}"]) <= 1e-5
+    zero = torch.zeros(1, 12, 16, 2, dtype=torch.float64, device=dev)
+    assert maxdiff(ev.warpFeature(feat, zero), g["out_zero"]) <= 1e-5
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 37, 53), (8, 5, 300), (256, 16, 32)])
+def test_warp_large_motion(dev, C, H, W):
+    from arseg_amd import _lib, ops
+    from oracle import cpu_ref
+
+    feat = rnd(5, 2, C, H, W)
+    g = np.random.Generator(np.random.PCG64(6))
+    flow = torch.from_numpy(g.uniform(-1.5 * W, 1.5 * W, (2, H, W, 2)))
+    want = cpu_ref.warp_feature(feat, flow)
+    got = ops.warp(feat.to(dev), flow.to(dev), _lib.NCHW).cpu()
+    assert maxdiff(got, want) <= 2e-5
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().to(dev)
+    got2 = ops.warp(nhwc, flow.to(dev), _lib.NHWC).permute(0, 3, 1, 2).cpu()
+    assert maxdiff(got2, want) <= 2e-5
+    got3 = ops.from_c8(ops.warp(nhwc, flow.float().to(dev), _lib.NHWC, _lib.C8), _lib.NCHW).cpu()
+    assert maxdiff(got3, cpu_ref.warp_feature(feat, flow.float())) <= 2e-5
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_mv_resize_golden(dev, golden, seed):
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops
+
+    g = golden(f"g2_mvresize_s{seed}")
+    mvq = t(g["mvq"]).to(dev)
+    for hp, wp in ((4, 6), (32, 48), (5, 7)):
+        out = ops.mv_resize(mvq, hp, wp)
+        assert out.dtype == torch.float64 and maxdiff(out, g[f"out_{hp}x{wp}"]) <= 1e-12
+        out2 = ev.resize_flow(mvq.double() / 4, hp, wp)
+        assert maxdiff(out2, g[f"out_{hp}x{wp}"]) <= 1e-12
+
+
+@pytest.mark.parametrize("H,W,Hp,Wp,C", [(32, 48, 32, 48, 8), (64, 96, 8, 12, 16), (40, 56, 5, 7, 8)])
+def test_warp_mvq_fused(dev, H, W, Hp, Wp, C):
+    from arseg_amd import _lib, ops
+    from oracle import cpu_ref
+
+    g = np.random.Generator(np.random.PCG64(9))
+    mvq = torch.from_numpy((g.integers(-12, 13, (1, H, W, 2)) * 4).astype(np.int16))
+    feat = rnd(10, 1, C, Hp, Wp)
+    want = cpu_ref.warp_feature(feat, cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq), Hp, Wp))
+    nhwc = feat.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.from_c8(ops.warp_mvq(nhwc, mvq.to(dev), _lib.C8), _lib.NCHW).cpu()
+    assert maxdiff(got, want) <= 1e-5
+    got2 = ops.warp_mvq(nhwc, mvq.to(dev), _lib.NHWC).permute(0, 3, 1, 2).cpu()
+    assert maxdiff(got2, want) <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------- CReFF
+@pytest.mark.parametrize("ci", range(5))
+@pytest.mark.parametrize("seed", [0, 1])
+def test_creff_golden(dev, golden, ci, seed):
+    from arseg_amd.model import MyAttention
+
+    g = golden(f"g3_attn_c{ci}_s{seed}")
+    k = int(g["k"])
+    C = g["hr"].shape[1]
+    m = MyAttention(C, kW=k, kH=k)
+    m.load_state_dict({kk[2:]: t(g[kk]) for kk in g.files if kk.startswith("w.")})
+    m = m.to(dev).eval()
+    out = m(t(g["hr"]).to(dev), t(g["lr"]).to(dev))
+    assert out.shape == g["out"].shape
+    assert maxdiff(out, g["out"]) <= 1e-4
+
+
+@pytest.mark.parametrize("C,Hp,Wp,hp,wp,k,n_cls,logsm", [
+    (64, 40, 70, 20, 35, 7, 12, True),      # PSPNet-like, ragged vs the 16x32 tile
+    (64, 16, 32, 8, 16, 7, 12, True),       # exactly one tile
+    (256, 19, 33, 10, 17, 7, 19, False),    # BiSeNet-like, small map -> short tiles
+    (8, 5, 6, 5, 6, 7, 0, False),           # image smaller than the window, same-size lr
+    (16, 33, 65, 11, 22, 5, 7, True),       # 5x5 window, generic class count
+    (8, 18, 34, 9, 17, 3, 0, False),        # 3x3 window
+    (32, 70, 40, 50, 80, 7, 32, False),     # lr larger than hr in one dim, 32 classes
+])
+def test_creff_vs_oracle(dev, C, Hp, Wp, hp, wp, k, n_cls, logsm):
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+    from oracle import cpu_ref
+
+    for N, gain in ((1, 0.35), (2, 1.0)):
+        m = synth.load_synth_weights(MyAttention(C, kW=k, kH=k), 7, attn_gain=gain)
+        sd = {kk: v.clone() for kk, v in m.state_dict().items()}
+        hr, lr = rnd(20, N, C, Hp, Wp), rnd(21, N, C, hp, wp)
+        want = cpu_ref.my_attention(sd, "", hr, lr, k, k)
+        pa = PackedAttention(m, dev)
+        head = None
+        if n_cls:
+            wf, bf = rnd(22, n_cls, C, scale=0.2), rnd(23, n_cls, scale=0.1)
+            head = (wf.to(dev), bf.to(dev))
+        p_c8, logits = ops.creff(ops.to_c8(hr.to(dev), _lib.NCHW), ops.to_nhwc(lr.to(dev)), pa, head, logsm, k, k)
+        tol = 1e-4 if gain < 1 else 3e-4      # gain 1.0: near one-hot softmax amplifies fp32 rounding of the scores
+        assert maxdiff(ops.from_c8(p_c8, _lib.NCHW), want) <= tol
+        if n_cls:
+            lg = F.conv2d(want, wf[:, :, None, None], bf)
+            if logsm:
+                lg = F.log_softmax(lg, dim=1)
+            assert maxdiff(logits, lg) <= 2 * tol
+        else:
+            assert logits is None
+
+
+def test_creff_padding_taps_take_softmax_mass(dev):
+    """Border semantics: taps outside the image score 0 and still receive softmax mass.  With a zero
+    query (all scores 0) the weights are uniform 1/49 over ALL taps, so a corner pixel keeps only 16/49 of a constant V."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.model import MyAttention
+
+    C = 8
+    m = MyAttention(C, kW=7, kH=7)
+    with torch.no_grad():
+        for conv in (m.lr_query_conv, m.hr_key_conv, m.hr_value_conv):
+            conv.weight.zero_()
+            conv.bias.zero_()
+        m.hr_value_conv.bias.fill_(1.0)          # V == 1 inside the image, 0 in the padding
+    m = m.to(dev).eval()
+    out = m(torch.zeros(1, C, 12, 40, device=dev), torch.zeros(1, C, 6, 20, device=dev)).cpu()
+    assert abs(float(out[0, 0, 0, 0]) - 16 / 49) <= 1e-6
+    assert abs(float(out[0, 0, 6, 20]) - 1.0) <= 1e-6
+    assert abs(float(out[0, 0, 0, 20]) - 28 / 49) <= 1e-6
+
+
+# ---------------------------------------------------------------------------------------------- conv engine
+CONV_CASES = [
+    # N, H,  W,  Cin, Cout, k, stride, pad, dil, act,  bn,    bias,  res
+    (1, 33, 47, 3, 64, 7, 2, 3, 1, "relu", True, False, False),      # stem (RGB padded to 4)
+    (1, 20, 24, 64, 64, 3, 1, 1, 1, "relu", True, False, True),      # BasicBlock conv2 + residual
+    (2, 17, 19, 64, 128, 3, 2, 1, 1, "relu", True, False, False),    # stride 2
+    (1, 12, 16, 128, 128, 1, 2, 0, 1, "none", True, False, False),   # 1x1 stride-2 downsample
+    (1, 10, 12, 256, 256, 3, 1, 2, 2, "relu", True, False, True),    # dilation 2
+    (1, 9, 11, 512, 512, 3, 1, 4, 4, "relu", True, False, False),    # dilation 4, deep K -> split-K
+    (1, 8, 12, 2560, 1024, 1, 1, 0, 1, "relu", False, True, False),  # PSP bottleneck (Cin not a power of two)
+    (1, 16, 24, 1024, 256, 3, 1, 1, 1, "prelu", True, True, False),  # up_1
+    (1, 30, 40, 64, 12, 1, 1, 0, 1, "none", False, True, False),     # Cout not a multiple of 4
+    (1, 1, 1, 256, 256, 1, 1, 0, 1, "sigmoid", True, False, False),  # attention vector (ARM / FFM)
+    (3, 1, 1, 256, 12, 1, 1, 0, 1, "none", False, True, False),      # linear classifier
+    (1, 40, 40, 64, 64, 3, 1, 1, 1, "prelu", True, True, False),     # up_3
+]
+
+
+def _conv_ref(x, w, b, bn, stride, pad, dil, act, slope, res):
+    y = F.conv2d(x, w, b, stride=stride, padding=pad, dilation=dil)
+    if bn is not None:
+        y = F.batch_norm(y, bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    if res is not None:
+        y = y + res
+    if act == "relu":
+        y = F.relu(y)
+    elif act == "prelu":
+        y = F.prelu(y, torch.tensor([slope]))
+    elif act == "sigmoid":
+        y = torch.sigmoid(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[3]}to{c[4]}k{c[5]}s{c[6]}d{c[8]}")
+def test_conv2d(dev, case):
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, use_bn, use_bias, use_res = case
+    g = np.random.Generator(np.random.PCG64(31))
+    x = rnd(30, N, Cin, H, W)
+    w = rnd(32, Cout, Cin, k, k, scale=float(np.sqrt(2.0 / (Cin * k * k))))
+    b = rnd(33, Cout, scale=0.1) if use_bias else None
+    bn = None
+    if use_bn:
+        bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(34, Cout, scale=0.1), rnd(35, Cout, scale=0.1),
+              t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    slope = 0.2
+    acts = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "prelu": _lib.ACT_PRELU, "sigmoid": _lib.ACT_SIGMOID}
+    pc = PackedConv(w, b, bn, stride, pad, dil, acts[act], slope, dev)
+    Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    res = rnd(36, N, Cout, Ho, Wo) if use_res else None
+    want = _conv_ref(x, w, b, bn, stride, pad, dil, act, slope, res)
+    xn = x.permute(0, 2, 3, 1).contiguous()
+    if Cin % 4:
+        xn = F.pad(xn, (0, 4 - Cin % 4))
+    xd = xn.to(dev)
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    tol = 2e-4
+    for tile_cfg, split_k in ((0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (3, 3), (1, 2)):
+        if split_k > 1 and Cout % 4:
+            continue
+        got = ops.conv2d(xd, pc, residual=rd, tile_cfg=tile_cfg, split_k=split_k).permute(0, 3, 1, 2).cpu()
+        assert got.shape == want.shape
+        assert maxdiff(got, want) <= tol, (tile_cfg, split_k)
+
+
+def test_conv2d_channel_slices(dev):
+    """in_ld / out_ld: read a channel slice of a wider NHWC buffer and write into one (zero-copy concat)."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    x_big = rnd(40, 1, 9, 13, 96)                 # NHWC, use channels 32..95
+    w = rnd(41, 32, 64, 3, 3, scale=0.05)
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    xd = x_big.to(dev)
+    out_big = torch.full((1, 9, 13, 80), 7.0, device=dev)
+    ops.conv2d(xd[..., 32:], pc, out=out_big[..., 16:48])
+    want = F.conv2d(x_big[..., 32:].permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
+    assert maxdiff(out_big[..., 16:48], want) <= 1e-4
+    assert float(out_big[..., :16].min()) == 7.0 and float(out_big[..., 48:].max()) == 7.0   # neighbours untouched
+
+
+def test_conv2d_rejects_bad_arguments(dev):
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    pc = PackedConv(rnd(42, 8, 24, 3, 3), None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)   # Cin=24: not a power of two with 3x3
+    with pytest.raises(_lib.ArsegError):
+        ops.conv2d(torch.zeros(1, 8, 8, 24, device=dev), pc)
+    pc2 = PackedConv(rnd(43, 8, 16, 3, 3), None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    with pytest.raises(_lib.ArsegError):
+        ops.conv2d(torch.zeros(1, 8, 8, 16), pc2)                                            # CPU tensor: no fallback
+
+
+# ---------------------------------------------------------------------------------------------- small layers
+@pytest.mark.parametrize("H,W,C", [(33, 47, 64), (8, 8, 4), (1, 5, 128)])
+def test_maxpool(dev, H, W, C):
+    from arseg_amd import ops
+
+    x = rnd(50, 2, C, H, W)
+    got = ops.maxpool3x3s2(x.permute(0, 2, 3, 1).contiguous().to(dev)).permute(0, 3, 1, 2)
+    assert maxdiff(got, F.max_pool2d(x, 3, 2, 1)) == 0.0
+
+
+@pytest.mark.parametrize("H,W,C,s", [(9, 12, 512, 1), (9, 12, 512, 2), (9, 12, 512, 3), (9, 12, 512, 6), (4, 5, 64, 6), (32, 64, 68, 3)])
+def test_adaptive_avgpool_and_global_reduce(dev, H, W, C, s):
+    from arseg_amd import _lib, ops
+
+    x = rnd(51, 2, C, H, W)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.adaptive_avgpool(xd, s, s).permute(0, 3, 1, 2)
+    assert maxdiff(got, F.adaptive_avg_pool2d(x, (s, s))) <= 1e-5
+    wide = torch.zeros(2, H, W, C + 8, device=dev)
+    wide[..., 8:] = xd
+    assert maxdiff(ops.adaptive_avgpool(wide[..., 8:], s, s).permute(0, 3, 1, 2), F.adaptive_avg_pool2d(x, (s, s))) <= 1e-5
+    assert maxdiff(ops.global_reduce(xd, _lib.REDUCE_MEAN).reshape(2, C), x.mean(dim=(2, 3))) <= 1e-5
+    assert maxdiff(ops.global_reduce(xd, _lib.REDUCE_MAX).reshape(2, C), x.amax(dim=(2, 3))) == 0.0
+
+
+@pytest.mark.parametrize("Hin,Win,Hout,Wout,mode,align", [
+    (6, 8, 12, 16, "bilinear", False), (1, 1, 9, 12, "bilinear", False), (3, 3, 9, 12, "bilinear", False),
+    (5, 7, 10, 14, "nearest", False), (10, 18, 9, 17, "bilinear", True), (9, 17, 10, 18, "bilinear", True),
+    (16, 32, 128, 256, "bilinear", False), (8, 16, 128, 256, "bilinear", False), (48, 64, 24, 32, "bilinear", True),
+    (7, 9, 7, 9, "bilinear", True), (5, 6, 13, 17, "bilinear", True)])
+def test_resize(dev, Hin, Win, Hout, Wout, mode, align):
+    from arseg_amd import _lib, ops
+
+    x = rnd(52, 2, 12, Hin, Win)
+    kw = dict(mode=mode) if mode == "nearest" else dict(mode=mode, align_corners=align)
+    want = F.interpolate(x, (Hout, Wout), **kw)
+    m = _lib.NEAREST if mode == "nearest" else _lib.BILINEAR
+    got = ops.resize_nchw(x.to(dev), Hout, Wout, m, align)
+    assert maxdiff(got, want) <= 1e-5
+    got2 = ops.resize_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev), Hout, Wout, m, align).permute(0, 3, 1, 2)
+    assert maxdiff(got2, want) <= 1e-5
+
+
+def test_scale_add_head_frame_layouts(dev):
+    from arseg_amd import _lib, ops
+
+    x = rnd(53, 2, 7, 9, 16)
+    sc, av, af = rnd(54, 2, 1, 1, 16), rnd(55, 2, 1, 1, 16), rnd(56, 2, 7, 9, 16)
+    assert maxdiff(ops.scale_add(x.to(dev), sc.to(dev), add_vec=av.to(dev)), x * sc + av) <= 1e-6
+    assert maxdiff(ops.scale_add(x.to(dev), sc.to(dev), add_full=af.to(dev)), x * sc + af) <= 1e-6
+    # head
+    for n_cls, logsm in ((12, True), (19, False), (5, True), (32, False)):
+        p = rnd(57, 2, 11, 13, 64)
+        wf, bf = rnd(58, n_cls, 64, scale=0.2), rnd(59, n_cls, scale=0.1)
+        want = F.conv2d(p.permute(0, 3, 1, 2), wf[:, :, None, None], bf)
+        if logsm:
+            want = F.log_softmax(want, dim=1)
+        assert maxdiff(ops.head(p.to(dev), wf.to(dev), bf.to(dev), logsm), want) <= 1e-4
+    # frame ingest with and without downscale
+    img = rnd(60, 2, 3, 20, 30)
+    same = ops.frame_to_nhwc4(img.to(dev), 20, 30).cpu()
+    assert maxdiff(same[..., :3], img.permute(0, 2, 3, 1)) == 0.0 and float(same[..., 3].abs().max()) == 0.0
+    small = ops.frame_to_nhwc4(img.to(dev), 10, 15).cpu()
+    assert maxdiff(small[..., :3].permute(0, 3, 1, 2), F.interpolate(img, (10, 15), mode="bilinear", align_corners=True)) <= 1e-5
+    # layout round trips
+    y = rnd(61, 2, 24, 5, 7)
+    nhwc = ops.to_nhwc(y.to(dev))
+    assert maxdiff(nhwc, y.permute(0, 2, 3, 1)) == 0.0
+    assert maxdiff(ops.to_nchw_contiguous(nhwc), y) == 0.0
+    assert maxdiff(ops.from_c8(ops.to_c8(y.to(dev), _lib.NCHW), _lib.NCHW), y) == 0.0
+    assert maxdiff(ops.from_c8(ops.to_c8(nhwc, _lib.NHWC), _lib.NHWC), y.permute(0, 2, 3, 1)) == 0.0
+    assert maxdiff(ops.from_c8(ops.to_c8(y.to(dev), _lib.NCHW), _lib.NHWC), y.permute(0, 2, 3, 1)) == 0.0
+
+
+@pytest.mark.parametrize("h,w,H,W", [(12, 16, 12, 16), (6, 8, 12, 16), (24, 32, 13, 17)])
+def test_argmax_confusion(dev, h, w, H, W):
+    from arseg_amd import ops
+    from oracle import cpu_ref
+
+    n_cls = 12
+    logits = rnd(62, 2, n_cls, h, w)
+    g = np.random.Generator(np.random.PCG64(63))
+    label = torch.from_numpy(g.integers(0, n_cls, (2, H, W)).astype(np.int64))
+    label[0, :2, :3] = 255
+    preds, hist = cpu_ref.eval_tail(logits, label, n_cls)
+    got_p, got_h = ops.argmax_confusion(logits.to(dev), label.to(dev), H, W)
+    assert (got_p.cpu().long() != preds).float().mean() <= 1e-3       # interpolation ties only
+    assert float((got_h.cpu().float() - hist).abs().sum()) <= 4
+    got_p2, got_h2 = ops.argmax_confusion(logits.to(dev), label.to(dev), H, W, hist=got_h.clone())
+    assert torch.equal(got_h2, 2 * got_h)                              # accumulates, deterministic
