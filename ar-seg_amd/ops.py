@@ -22,6 +22,51 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# ----------------------------------------------------------------------------------------------
+# optional per-launch timing (bench.py): HIP events on the launch stream around every ABI call
+# ----------------------------------------------------------------------------------------------
+_profile = None
+
+
+class profile:
+    """``with ops.profile() as prof: ...`` records (op name, algorithmic flops, algorithmic bytes, ms) per launch.
+    Events are recorded on torch's current stream, which is the stream handed to the library."""
+
+    def __enter__(self):
+        global _profile
+        self.records = []
+        _profile = self
+        return self
+
+    def __exit__(self, *exc):
+        global _profile
+        _profile = None
+        torch.cuda.synchronize()
+        self.rows = [(name, flops, nbytes, s.elapsed_time(e)) for name, flops, nbytes, s, e in self.records]
+        return False
+
+    def summary(self):
+        out = {}
+        for name, flops, nbytes, ms in self.rows:
+            r = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0, "bytes": 0})
+            r["launches"] += 1
+            r["ms"] += ms
+            r["flops"] += flops
+            r["bytes"] += nbytes
+        return out
+
+
+def _launch(name, fn, *args, flops=0, nbytes=0):
+    if _profile is None:
+        check(fn(*args), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(fn(*args), name)
+    e.record()
+    _profile.records.append((name, flops, nbytes, s, e))
+
+
 def _need_gpu(*tensors, dtype=torch.float32):
     for t in tensors:
         if t is None:
@@ -68,7 +113,7 @@ def to_nhwc(x: torch.Tensor) -> torch.Tensor:
         return x.permute(0, 2, 3, 1)
     x = x.contiguous()
     out = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_nchw_to_nhwc_fwd(_ptr(x), _ptr(out), N, C, H * W, C, _stream()), "nchw_to_nhwc")
+    _launch("nchw_to_nhwc", _lib.load().arseg_nchw_to_nhwc_fwd, _ptr(x), _ptr(out), N, C, H * W, C, _stream())
     return out
 
 
@@ -81,7 +126,7 @@ def to_nchw_contiguous(x_nhwc: torch.Tensor) -> torch.Tensor:
     _need_gpu(x_nhwc)
     N, H, W, C = x_nhwc.shape
     out = torch.empty((N, C, H, W), dtype=torch.float32, device=x_nhwc.device)
-    check(_lib.load().arseg_nhwc_to_nchw_fwd(_ptr(x_nhwc), C, _ptr(out), N, C, H * W, _stream()), "nhwc_to_nchw")
+    _launch("nhwc_to_nchw", _lib.load().arseg_nhwc_to_nchw_fwd, _ptr(x_nhwc), C, _ptr(out), N, C, H * W, _stream())
     return out
 
 
@@ -97,7 +142,7 @@ def to_c8(x: torch.Tensor, layout: int) -> torch.Tensor:
         x = x.contiguous()
         ld = C
     out = torch.empty((N, C // 8, H, W, 8), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_to_c8_fwd(_ptr(x), layout, ld, _ptr(out), N, C, H * W, _stream()), "to_c8")
+    _launch("to_c8", _lib.load().arseg_to_c8_fwd, _ptr(x), layout, ld, _ptr(out), N, C, H * W, _stream())
     return out
 
 
@@ -107,7 +152,7 @@ def from_c8(x: torch.Tensor, layout: int) -> torch.Tensor:
     C = CB * 8
     shape = (N, C, H, W) if layout == _lib.NCHW else (N, H, W, C)
     out = torch.empty(shape, dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_from_c8_fwd(_ptr(x), _ptr(out), layout, C, N, C, H * W, _stream()), "from_c8")
+    _launch("from_c8", _lib.load().arseg_from_c8_fwd, _ptr(x), _ptr(out), layout, C, N, C, H * W, _stream())
     return out
 
 
@@ -119,7 +164,7 @@ def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.T
     q, k = q.contiguous(), k.contiguous()
     N, C, H, W = q.shape
     out = torch.empty((N, H, W, kH * kW), dtype=torch.float32, device=q.device)
-    check(_lib.load().arseg_local_similar_fwd(_ptr(q), _ptr(k), _ptr(out), N, C, H, W, kH, kW, _stream()), "local_similar")
+    _launch("local_similar", _lib.load().arseg_local_similar_fwd, _ptr(q), _ptr(k), _ptr(out), N, C, H, W, kH, kW, _stream())
     return out
 
 
@@ -128,7 +173,7 @@ def local_weighting(v: torch.Tensor, w: torch.Tensor, kH: int, kW: int) -> torch
     v, w = v.contiguous(), w.contiguous()
     N, C, H, W = v.shape
     out = torch.empty_like(v)
-    check(_lib.load().arseg_local_weighting_fwd(_ptr(v), _ptr(w), _ptr(out), N, C, H, W, kH, kW, _stream()), "local_weighting")
+    _launch("local_weighting", _lib.load().arseg_local_weighting_fwd, _ptr(v), _ptr(w), _ptr(out), N, C, H, W, kH, kW, _stream())
     return out
 
 
@@ -152,7 +197,7 @@ def warp(feature: torch.Tensor, flow: torch.Tensor, layout: int, out_layout: Opt
     else:
         out = torch.empty_like(feature)
     fd = _lib.FLOW_F64 if flow.dtype == torch.float64 else _lib.FLOW_F32
-    check(_lib.load().arseg_warp_fwd(_ptr(feature), _ptr(flow), fd, _ptr(out), N, C, H, W, layout, out_layout, _stream()), "warp")
+    _launch("warp", _lib.load().arseg_warp_fwd, _ptr(feature), _ptr(flow), fd, _ptr(out), N, C, H, W, layout, out_layout, _stream())
     return out
 
 
@@ -162,7 +207,7 @@ def mv_resize(mv_q: torch.Tensor, Hp: int, Wp: int) -> torch.Tensor:
     mv_q = mv_q.contiguous()
     N, H, W, _ = mv_q.shape
     out = torch.empty((N, Hp, Wp, 2), dtype=torch.float64, device=mv_q.device)
-    check(_lib.load().arseg_mv_resize_fwd(_ptr(mv_q), _ptr(out), N, H, W, Hp, Wp, _stream()), "mv_resize")
+    _launch("mv_resize", _lib.load().arseg_mv_resize_fwd, _ptr(mv_q), _ptr(out), N, H, W, Hp, Wp, _stream())
     return out
 
 
@@ -175,8 +220,8 @@ def warp_mvq(feature_nhwc: torch.Tensor, mv_q: torch.Tensor, out_layout: int = _
     _, H, W, _ = mv_q.shape
     shape = (N, C // 8, Hp, Wp, 8) if out_layout == _lib.C8 else (N, Hp, Wp, C)
     out = torch.empty(shape, dtype=torch.float32, device=feature_nhwc.device)
-    check(_lib.load().arseg_warp_mvq_fwd(_ptr(feature_nhwc), _ptr(mv_q), _ptr(out), N, C, Hp, Wp, H, W, out_layout, _stream()),
-          "warp_mvq")
+    _launch("warp_mvq", _lib.load().arseg_warp_mvq_fwd, _ptr(feature_nhwc), _ptr(mv_q), _ptr(out), N, C, Hp, Wp, H, W, out_layout, _stream(),
+            nbytes=N * (2 * 4 * C * Hp * Wp + 4 * H * W))
     return out
 
 
@@ -200,9 +245,11 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
         wf, bf = head
         n_cls = wf.shape[0]
         logits = torch.empty((N, n_cls, Hp, Wp), dtype=torch.float32, device=hr_c8.device)
-    check(_lib.load().arseg_creff_fwd(_ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
+    _launch("creff", _lib.load().arseg_creff_fwd, _ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
                                       _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
-                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, _stream()), "creff")
+                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, _stream(),
+            flops=N * Hp * Wp * C * (250 + 2 * n_cls),
+            nbytes=4 * N * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp))
     return p_out, logits
 
 
@@ -257,8 +304,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         d.res_ld = _nhwc_ld(residual)
     nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
     ws = workspace(nbytes, x.device) if nbytes else None
-    check(lib.arseg_conv2d_fwd(ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out),
-                               _ptr(ws), nbytes, _stream()), "conv2d")
+    _launch("conv2d", lib.arseg_conv2d_fwd, ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual),
+            _ptr(out), _ptr(ws), nbytes, _stream(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
     return out
 
 
@@ -270,7 +317,7 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     x = x.contiguous()
     N, H, W, C = x.shape
     out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_maxpool3x3s2_fwd(_ptr(x), _ptr(out), N, H, W, C, _stream()), "maxpool")
+    _launch("maxpool", _lib.load().arseg_maxpool3x3s2_fwd, _ptr(x), _ptr(out), N, H, W, C, _stream())
     return out
 
 
@@ -278,7 +325,7 @@ def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
     _need_gpu(x)
     N, H, W, C = x.shape
     out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_adaptive_avgpool_fwd(_ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, oh, ow, _stream()), "adaptive_avgpool")
+    _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, oh, ow, _stream())
     return out
 
 
@@ -287,7 +334,7 @@ def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
     _need_gpu(x)
     N, H, W, C = x.shape
     out = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_global_reduce_fwd(_ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, op, _stream()), "global_reduce")
+    _launch("global_reduce", _lib.load().arseg_global_reduce_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, op, _stream())
     return out
 
 
@@ -296,8 +343,8 @@ def resize_nhwc(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners:
     N, H, W, C = x.shape
     if out is None:
         out = torch.empty((N, Hout, Wout, C), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_resize_fwd(_ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NHWC,
-                                       _nhwc_ld(x), _nhwc_ld(out), _stream()), "resize_nhwc")
+    _launch("resize_nhwc", _lib.load().arseg_resize_fwd, _ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NHWC,
+                                       _nhwc_ld(x), _nhwc_ld(out), _stream())
     return out
 
 
@@ -306,8 +353,8 @@ def resize_nchw(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners:
     x = x.contiguous()
     N, C, H, W = x.shape
     out = torch.empty((N, C, Hout, Wout), dtype=torch.float32, device=x.device)
-    check(_lib.load().arseg_resize_fwd(_ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NCHW, 0, 0,
-                                       _stream()), "resize_nchw")
+    _launch("resize_nchw", _lib.load().arseg_resize_fwd, _ptr(x), _ptr(out), N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0, _lib.NCHW, 0, 0,
+                                       _stream())
     return out
 
 
@@ -320,9 +367,8 @@ def scale_add(x: torch.Tensor, scale: torch.Tensor, add_full: Optional[torch.Ten
     out = torch.empty_like(x)
     if add_full is not None:
         add_full = add_full.contiguous()
-    check(_lib.load().arseg_scale_add_fwd(_ptr(x), _ptr(scale.contiguous()), _ptr(add_full),
-                                          _ptr(None if add_vec is None else add_vec.contiguous()), _ptr(out), N, H * W, C, _stream()),
-          "scale_add")
+    _launch("scale_add", _lib.load().arseg_scale_add_fwd, _ptr(x), _ptr(scale.contiguous()), _ptr(add_full),
+                                          _ptr(None if add_vec is None else add_vec.contiguous()), _ptr(out), N, H * W, C, _stream())
     return out
 
 
@@ -332,8 +378,8 @@ def head(p_nhwc: torch.Tensor, wf: torch.Tensor, bf: torch.Tensor, log_softmax: 
     N, H, W, C = p_nhwc.shape
     n_cls = wf.shape[0]
     out = torch.empty((N, n_cls, H, W), dtype=torch.float32, device=p_nhwc.device)
-    check(_lib.load().arseg_head_fwd(_ptr(p_nhwc), _nhwc_ld(p_nhwc), _ptr(wf), _ptr(bf), _ptr(out), N, H * W, C, n_cls,
-                                     1 if log_softmax else 0, _stream()), "head")
+    _launch("head", _lib.load().arseg_head_fwd, _ptr(p_nhwc), _nhwc_ld(p_nhwc), _ptr(wf), _ptr(bf), _ptr(out), N, H * W, C, n_cls,
+                                     1 if log_softmax else 0, _stream())
     return out
 
 
@@ -345,7 +391,7 @@ def frame_to_nhwc4(img: torch.Tensor, h: int, w: int) -> torch.Tensor:
     if C != 3:
         raise _lib.ArsegError("frame_to_nhwc4 expects 3 input channels")
     out = torch.empty((N, h, w, 4), dtype=torch.float32, device=img.device)
-    check(_lib.load().arseg_frame_to_nhwc4_fwd(_ptr(img), _ptr(out), N, H, W, h, w, _stream()), "frame_to_nhwc4")
+    _launch("frame_to_nhwc4", _lib.load().arseg_frame_to_nhwc4_fwd, _ptr(img), _ptr(out), N, H, W, h, w, _stream())
     return out
 
 
@@ -361,6 +407,6 @@ def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int
         label = label.contiguous()
         if hist is None:
             hist = torch.zeros((n_cls, n_cls), dtype=torch.int64, device=logits.device)
-    check(_lib.load().arseg_argmax_confusion_fwd(_ptr(logits), _ptr(label), _ptr(pred), _ptr(hist if label is not None else None), N,
-                                                 n_cls, h, w, H, W, ignore_label, _stream()), "argmax_confusion")
+    _launch("argmax_confusion", _lib.load().arseg_argmax_confusion_fwd, _ptr(logits), _ptr(label), _ptr(pred), _ptr(hist if label is not None else None), N,
+                                                 n_cls, h, w, H, W, ignore_label, _stream())
     return pred, hist

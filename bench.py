@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- AR-Seg LR-branch hot path on MI355X: non-keyframe frames/s on synthetic GOP-12 clips.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): PSPNet-18, keyframe HR branch at
+512x1024, 11 non-keyframes per GOP through the LR branch (0.5x -> 256x512 backbone) + CReFF at 512x1024, fp32.
+
+A "step" is one GOP per rank, i.e. one pass of the hot path over one batch of synthetic input:
+    keyframe HR forward -> (N > 1: RCCL all-gather of ref_p) -> 11 x [frame downscale + NHWC ingest, LR backbone,
+    MV resize + warp, fused CReFF + classifier + log-softmax]
+All inputs (frames, int16 MV maps, weights) are resident in HBM before the timed region.  `value` counts the
+non-keyframes only, while the keyframe's HR forward and the exchange are inside the timed region (nothing skipped).
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the fp32-MFMA implicit-GEMM conv), `roofline_creff`
+(warp + CReFF stage against the HBM roofline, algorithmic bytes of SURVEY.md section 8d), `cpu_baseline` (the oracle,
+i.e. a port, timed on the host cores for one non-keyframe of the same clip) and `parity` (max-abs error and argmax
+agreement of that frame against the oracle).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+H, W, GOP, SCALE, N_CLS = 512, 1024, 12, 0.5, 12
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+
+
+def build_nets(dev):
+    from arseg_amd import synth
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    sd_hr = {k: v.clone() for k, v in hr.state_dict().items()}
+    sd_lr = {k: v.clone() for k, v in lr.state_dict().items()}
+    return hr.to(dev).eval(), lr.to(dev).eval(), sd_hr, sd_lr
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the (slow) CPU oracle leg")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from arseg_amd import _lib, evaluation as ev, ops, synth
+    from arseg_amd.gop import GopRunner
+
+    _lib.load()
+    hr, lr, sd_hr, sd_lr = build_nets(dev)
+
+    # ---- synthetic batch: `world` GOPs; this rank owns keyframe `rank` and 11 round-robin non-keyframes
+    def key_fn(key_img):
+        return ops.to_nhwc(hr(key_img)[-1])[0]                        # ref_p, NHWC [Hp,Wp,C]
+
+    def nonkey_fn(ref_p, img, mvq):
+        out, p_c8 = ev.alter_res_step_fast(lr, ref_p.unsqueeze(0), img, mvq, SCALE)
+        return out
+
+    runner = GopRunner(key_fn, nonkey_fn, n_gops=world, gop=GOP)
+    clips = {}
+    needed = set(runner.my_gops) | {g for g, _ in runner.plan}
+    for g in sorted(needed):
+        clips[g] = synth.make_clip(g, H, W, gop=GOP)
+    keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
+    frames = {(g, d): torch.from_numpy(clips[g]["frames"][d:d + 1]).to(dev) for g, d in runner.plan}
+    mvs = {(g, d): torch.from_numpy(clips[g]["mv"][d:d + 1]).to(dev) for g, d in runner.plan}
+
+    def step():
+        with torch.no_grad():
+            return runner.run(keyframes, frames, mvs)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+
+    nonkey_per_step = world * (GOP - 1)
+    result = {
+        "metric": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
+        "value": nonkey_per_step * args.steps / elapsed,
+        "unit": "frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "PSPNet-18 HR keyframe 512x1024 + 11 non-keyframes LR 0.5x (256x512) + CReFF 7x7 @512x1024, "
+                               "GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32",
+                   "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
+                   "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
+        "all_frames_per_s": world * GOP * args.steps / elapsed,
+    }
+
+    # ---- per-kernel timing with HIP events on the launch stream (one extra, instrumented step)
+    if rank == 0 and not args.no_profile:
+        g0, d0 = runner.plan[0]
+        with torch.no_grad():
+            ref_p = key_fn(keyframes[runner.my_gops[0]])
+            with ops.profile() as prof_key:
+                key_fn(keyframes[runner.my_gops[0]])
+            with ops.profile() as prof_nk:
+                for _ in range(3):
+                    nonkey_fn(ref_p, frames[(g0, d0)], mvs[(g0, d0)])
+        nk = prof_nk.summary()
+        ky = prof_key.summary()
+        conv = nk["conv2d"]
+        conv_k = ky["conv2d"]
+        tf = lambda r: r["flops"] / (r["ms"] * 1e-3) / 1e12
+        # dominant kernel of the step: conv_igemm_f32 (11 LR frames + 1 HR frame)
+        tot_flops = conv["flops"] / 3 * (GOP - 1) + conv_k["flops"]
+        tot_ms = conv["ms"] / 3 * (GOP - 1) + conv_k["ms"]
+        n_launch = conv["launches"] / 3 * (GOP - 1) + conv_k["launches"]
+        result["roofline"] = {
+            "kernel": "conv_igemm_f32_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            "bound": "mfma", "achieved": tot_flops / (tot_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": None,
+            "per_launch": {"avg_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
+            "lr_frame_tflops": tf(conv), "hr_frame_tflops": tf(conv_k),
+        }
+        cre, wrp = nk["creff"], nk["warp_mvq"]
+        # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
+        stage_bytes = 4 * 64 * H * W + 4 * 64 * (H // 2) * (W // 2) + 4 * 64 * H * W + 4 * H * W + 4 * N_CLS * H * W
+        stage_ms = (cre["ms"] + wrp["ms"]) / 3
+        result["roofline_creff"] = {
+            "kernel": "warp_mvq_nhwc_kernel + creff_kernel<7,12,16> (MV warp + fused CReFF + classifier)",
+            "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
+            "algorithmic_bytes_per_frame": stage_bytes, "warp_ms": wrp["ms"] / 3, "creff_ms": cre["ms"] / 3,
+            "creff_kernel_gflops": cre["flops"] / 3 / (cre["ms"] / 3 * 1e-3) / 1e9,
+        }
+        result["per_frame_ms"] = {"lr_frame_by_op": {k: v["ms"] / 3 for k, v in sorted(nk.items())},
+                                  "hr_keyframe_by_op": {k: v["ms"] for k, v in sorted(ky.items())}}
+
+    # ---- CPU baseline (rank 0, N=1 only): the oracle (a port) on one non-keyframe of the same clip; also the parity check
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cpu_ref
+
+        ncores = os.cpu_count() or 1
+        torch.set_num_threads(ncores)
+        g0, d0 = runner.plan[0]
+        img = torch.from_numpy(clips[g0]["frames"][d0:d0 + 1])
+        key = torch.from_numpy(clips[g0]["frames"][0:1])
+        mvq = torch.from_numpy(clips[g0]["mv"][d0:d0 + 1])
+        with torch.no_grad():
+            ref_cpu = cpu_ref.pspnet_forward(sd_hr, key)[-1]                      # outside the timed sample
+            t1 = time.perf_counter()
+            o_out, o_p, _, _ = cpu_ref.alter_res_step("psp", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
+            cpu_s = time.perf_counter() - t1
+        got = outs[(g0, d0)].cpu()
+        ref_gpu = ops.as_nchw(key_fn(keyframes[g0]).unsqueeze(0)).cpu()
+        result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": "1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same "
+                                            "512x1024 clip with the PyTorch-CPU oracle; keyframe feature precomputed outside the sample",
+                                  "seconds": cpu_s}
+        result["parity"] = {"max_abs_err_logprobs": float((got - o_out).abs().max()),
+                            "max_abs_err_keyframe_feature": float((ref_gpu - ref_cpu).abs().max()),
+                            "argmax_agreement": float((got.argmax(1) == o_out.argmax(1)).float().mean()),
+                            "tolerance": 1e-3}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,75 @@
+"""Host logic of the multi-GPU GOP runner, on CPU: the frame plan, and a world_size-2 gloo run whose
+outputs must equal the single-process run bit for bit (sharding is by frame, no arithmetic changes)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from arseg_amd.gop import GopRunner, frame_plan, keyframe_owner
+
+
+def test_frame_plan_covers_every_frame_once():
+    for world in (1, 2, 4, 8):
+        plan = frame_plan(world, 12, world)
+        flat = [f for r in plan for f in r]
+        assert len(flat) == len(set(flat)) == world * 11
+        assert all(len(r) == 11 for r in plan)                      # balanced: every rank gets gop-1 frames
+        assert {g for g, _ in flat} == set(range(world)) and {d for _, d in flat} == set(range(1, 12))
+    assert keyframe_owner(5, 4) == 1
+
+
+def _key_fn(k):
+    return torch.tanh(k * 1.5) + 0.25
+
+
+def _nonkey_fn(ref, frame, mv):
+    return ref * frame.mean() + mv.float().sum() * 1e-3 + frame
+
+
+def _data(n_gops, gop=12):
+    g = torch.Generator().manual_seed(1)
+    keys = {i: torch.randn(3, 8, 8, generator=g) for i in range(n_gops)}
+    frames = {(i, d): torch.randn(3, 8, 8, generator=g) for i in range(n_gops) for d in range(1, gop)}
+    mvs = {(i, d): torch.randint(-8, 8, (8, 8, 2), generator=g).to(torch.int16) for i in range(n_gops) for d in range(1, gop)}
+    return keys, frames, mvs
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    keys, frames, mvs = _data(world)
+    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=world)
+    out = runner.run({g: keys[g] for g in runner.my_gops}, {f: frames[f] for f in runner.plan}, {f: mvs[f] for f in runner.plan})
+    hist = torch.tensor([float(len(out))])
+    dist.all_reduce(hist)                                            # the confusion-matrix reduction pattern
+    q.put((rank, {k: v.clone() for k, v in out.items()}, float(hist)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    keys, frames, mvs = _data(world)
+    single = GopRunner(_key_fn, _nonkey_fn, n_gops=world).run(keys, frames, mvs)     # no process group -> world 1
+    merged = {}
+    for _, out, total in results:
+        assert total == world * 11
+        merged.update(out)
+    assert set(merged) == set(single)
+    for k in single:
+        assert torch.equal(merged[k], single[k])
