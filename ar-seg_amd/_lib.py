@@ -10,7 +10,7 @@ import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libarseg_hip.so")
+LIB_PATH = os.environ.get("ARSEG_HIP_LIB", os.path.join(_HERE, "lib", "libarseg_hip.so"))   # env override: kernel experiments
 
 ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3

@@ -240,33 +240,39 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->ktiles = pl->Kpad / BK;
 
     static const int cfg[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
-    int bm, bn;
+    // Tile / split-K choice, fitted to a brute-force sweep of this model family's layer shapes on MI355X
+    // (scratch sweep recorded in DESIGN.md): aim for ~512 workgroups (2 per CU); take the largest tile that gets
+    // there with a split-K factor that still leaves >= 8 K-steps per slice; shallow GEMMs (< 64 K-steps) are best
+    // served by 64x64 tiles.
+    const int target = 512;
+    const int max_split = pl->ktiles / 8 > 0 ? (pl->ktiles / 8 > 16 ? 16 : pl->ktiles / 8) : 1;
+    int bm = 64, bn = 64, nsplit = 1;
     if (d->tile_cfg >= 1 && d->tile_cfg <= 4) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
     else {
-        // largest tile that still gives >= 2 blocks per CU (256 CUs); small problems fall to 64x64 (+ split-K)
-        const int order[4] = {1, 2, 4, 3};
-        bm = 64; bn = 64;
-        for (int t = 0; t < 4; ++t) {
+        const int order_deep[4] = {1, 4, 2, 3}, order_shallow[4] = {3, 3, 3, 3};
+        const int *order = pl->ktiles >= 64 ? order_deep : order_shallow;
+        bool found = false;
+        for (int t = 0; t < 4 && !found; ++t) {
             const int tb_m = cfg[order[t]][0], tb_n = cfg[order[t]][1];
             if (tb_n == 128 && d->Cout <= 64) continue;
             if (tb_m == 128 && M <= 64) continue;
-            const long long blocks = (long long)arseg_cdiv(M, tb_m) * arseg_cdiv(d->Cout, tb_n);
-            if (blocks >= 512) { bm = tb_m; bn = tb_n; break; }
+            const long long tiles = (long long)arseg_cdiv(M, tb_m) * arseg_cdiv(d->Cout, tb_n);
+            const long long need = (target + tiles - 1) / tiles;
+            if (need <= max_split || order[t] == 3) {
+                bm = tb_m; bn = tb_n;
+                nsplit = (int)(need < 1 ? 1 : (need > max_split ? max_split : need));
+                found = true;
+            }
         }
     }
     pl->bm = bm; pl->bn = bn;
     pl->tiles_m = arseg_cdiv(M, bm);
     pl->tiles_n = arseg_cdiv(d->Cout, bn);
-    int nsplit = d->split_k;
-    if (nsplit <= 0) {
-        const long long blocks = (long long)pl->tiles_m * pl->tiles_n;
-        nsplit = 1;
-        if (blocks < 384) {
-            nsplit = (int)((512 + blocks - 1) / blocks);
-            const int max_by_k = pl->ktiles / 8 > 0 ? pl->ktiles / 8 : 1;   // keep >= 8 K steps per slice
-            if (nsplit > max_by_k) nsplit = max_by_k;
-            if (nsplit > 16) nsplit = 16;
-        }
+    if (d->split_k > 0) nsplit = d->split_k;
+    else if (d->tile_cfg >= 1 && d->tile_cfg <= 4) {
+        const long long tiles = (long long)pl->tiles_m * pl->tiles_n;
+        const long long need = (target + tiles - 1) / tiles;
+        nsplit = (int)(need < 1 ? 1 : (need > max_split ? max_split : need));
     }
     if (nsplit > pl->ktiles) nsplit = pl->ktiles;
     if (nsplit > 1 && (d->Cout & 3)) nsplit = 1;   // the reduce kernel is 4-wide

@@ -83,21 +83,33 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
     constexpr int LH = TH + 2, LWD = TW + 2, LPL = LH * LWD + PAD;                   // lr_up tile (+1 halo)
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     f32x4 *Hs = smem4, *Ks = Hs + G * HPL, *Ls = Ks + G * KPL, *Wd = Ls + G * LPL;   // Wd: [3][10][G] (9 taps + bias)
+    f32x4 *Wf = Wd + 3 * 10 * G;                                                  // classifier [n_cls][C/4], staged once
 
     const int tid = threadIdx.x, lx = tid & 31, yp = tid >> 5;
     const int n = blockIdx.z, ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const int CB = p.C >> 3;
     const int px = tx0 + lx, py0 = ty0 + 2 * yp;
 
+    // The staging loops have compile-time trip counts and are fully unrolled so that every global load of a
+    // phase is in flight at once (with a `tid`-bounded loop hipcc issues them one at a time and the kernel
+    // becomes latency bound at 2 waves per SIMD).
     auto stage_hr = [&](int cb, int tid) {
         const float *src = p.hr + ((size_t)n * CB + cb) * p.Hp * p.Wp * 8;
-        for (int i = tid; i < G * HH * HWD; i += NT) {
+        constexpr int TOT = G * HH * HWD, NI = (TOT + NT - 1) / NT;
+        f32x4 v[NI];
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * NT;
             const int g = i & 1, pc = i >> 1, r = pc / HWD, c = pc - r * HWD;
             const int gy = ty0 - (R + 1) + r, gx = tx0 - (R + 1) + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)
-                v = *reinterpret_cast<const f32x4 *>(src + ((size_t)gy * p.Wp + gx) * 8 + g * 4);
-            Hs[g * HPL + pc] = v;
+            v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)
+                v[it] = *reinterpret_cast<const f32x4 *>(src + ((size_t)gy * p.Wp + gx) * 8 + g * 4);
+        }
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int i = tid + it * NT;
+            if (i < TOT) Hs[(i & 1) * HPL + (i >> 1)] = v[it];
         }
     };
     auto stage_dw = [&](int cb, int tid) {   // depthwise weights + biases of this chunk: Wd[conv][tap(9)=bias][g]
@@ -109,22 +121,27 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
             Wd[i] = t < 9 ? *reinterpret_cast<const f32x4 *>(w + (size_t)t * p.C + c) : *reinterpret_cast<const f32x4 *>(b + c);
         }
     };
-    // K or V tile = bias + dw3x3(Hs), zero outside the image
+    // K or V tile = bias + dw3x3(Hs), zero outside the image (select, no branch: the Hs halo is zero filled, so the
+    // reads are always in range); static trip count, unrolled by two so that two items' LDS reads overlap.
     auto conv_tile = [&](int cv, int tid) {
-        for (int i = tid; i < G * KH * KWD; i += NT) {
+        constexpr int TOT = G * KH * KWD, NI = (TOT + NT - 1) / NT;
+#pragma unroll 2
+        for (int it = 0; it < NI; ++it) {
+            const int i = min(tid + it * NT, TOT - 1);          // the surplus lanes of the last round redo the last item
             const int g = i / (KH * KWD), pc = i - g * (KH * KWD), r = pc / KWD, c = pc - r * KWD;
             const int gy = ty0 - R + r, gx = tx0 - R + c;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) {
-                acc = Wd[(cv * 10 + 9) * G + g];
+            f32x4 acc = Wd[(cv * 10 + 9) * G + g];
 #pragma unroll
-                for (int dy = 0; dy < 3; ++dy)
+            for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                    for (int dx = 0; dx < 3; ++dx) acc += Wd[(cv * 10 + dy * 3 + dx) * G + g] * Hs[g * HPL + (r + dy) * HWD + c + dx];
-            }
+                for (int dx = 0; dx < 3; ++dx) acc += Wd[(cv * 10 + dy * 3 + dx) * G + g] * Hs[g * HPL + (r + dy) * HWD + c + dx];
+            if (!((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
             Ks[g * KPL + pc] = acc;
         }
     };
+
+    if (NC > 0)
+        for (int i = tid; i < p.n_cls * (p.C >> 2); i += NT) Wf[i] = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)i * 4);
 
     float S0[T], S1[T];
 #pragma unroll
@@ -142,12 +159,24 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
         asm volatile("" : "+v"(t));
         stage_hr(cb, t);
         stage_dw(cb, t);
-        for (int i = t; i < G * LH * LWD; i += NT) {
-            const int g = i & 1, pc = i >> 1, r = pc / LWD, c = pc - r * LWD;
-            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp) v = lr_up_at(p, n, gy, gx, cb * 8 + g * 4);
-            Ls[g * LPL + pc] = v;
+        {
+            constexpr int TOT = G * LH * LWD, NI = (TOT + NT - 1) / NT;
+            f32x4 v[NI];
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = t + it * NT;
+                const int g = i & 1, pc = i >> 1, r = pc / LWD, c = pc - r * LWD;
+                const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+                const bool ok = i < TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
+                // clamped coordinates keep the gathers in range; lanes outside the image are zeroed afterwards
+                v[it] = lr_up_at(p, n, min(max(gy, 0), p.Hp - 1), min(max(gx, 0), p.Wp - 1), cb * 8 + g * 4);
+                if (!ok) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int it = 0; it < NI; ++it) {
+                const int i = t + it * NT;
+                if (i < TOT) Ls[(i & 1) * LPL + (i >> 1)] = v[it];
+            }
         }
         __syncthreads();
         conv_tile(1, t);
@@ -184,11 +213,15 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
 #pragma unroll
                     for (int dx = 0; dx < KS; ++dx) kv[(r + 1) & 1][dx] = base[off + dx];
                 }
+                // component-major: consecutive FMAs hit different accumulators (a dot4 per tap would be a
+                // 4-deep dependent chain issued back to back, stalling the in-order VALU)
 #pragma unroll
-                for (int dx = 0; dx < KS; ++dx) {
-                    if (r < KS) S0[r * KS + dx] = dot4(q[0][g], kv[r & 1][dx], S0[r * KS + dx]);
-                    if (r >= 1) S1[(r - 1) * KS + dx] = dot4(q[1][g], kv[r & 1][dx], S1[(r - 1) * KS + dx]);
-                }
+                for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+                    for (int dx = 0; dx < KS; ++dx) {
+                        if (r < KS) S0[r * KS + dx] = fmaf(q[0][g][c4], kv[r & 1][dx][c4], S0[r * KS + dx]);
+                        if (r >= 1) S1[(r - 1) * KS + dx] = fmaf(q[1][g][c4], kv[r & 1][dx][c4], S1[(r - 1) * KS + dx]);
+                    }
                 tie = r < KS ? S0[r * KS + KS - 1] : S1[(r - 1) * KS + KS - 1];
             }
         }
@@ -226,6 +259,13 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
         asm volatile("" : "+v"(t));
         stage_hr(cb, t);
         stage_dw(cb, t);
+        // residual term for this thread's two pixels: issue the gathers now so that their latency hides under the
+        // value conv and the PV walk
+        f32x4 lrv[2][G];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < G; ++g) lrv[j][g] = lr_up_at(p, n, min(py0 + j, p.Hp - 1), min(px, p.Wp - 1), cb * 8 + g * 4);
         __syncthreads();
         conv_tile(2, t);
         __syncthreads();
@@ -262,13 +302,13 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
             const int gy = min(py0 + j, p.Hp - 1), gx = min(px, p.Wp - 1);
 #pragma unroll
             for (int g = 0; g < G; ++g) {
-                const f32x4 o = lr_up_at(p, n, gy, gx, cb * 8 + g * 4) + a[j][g];
+                const f32x4 o = lrv[j][g] + a[j][g];
                 const unsigned off = (unsigned)((((((size_t)n * CB + cb) * p.Hp + gy) * p.Wp + gx) * 8 + g * 4) * sizeof(float));
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, (j == 0 ? in0 : in1) ? off : 0xFFFFFFF0u, 0, 0);
                 if (NC > 0) {
 #pragma unroll
-                    for (int k = 0; k < NCA; ++k) {   // branch-free: class rows past n_cls re-read the last row
-                        const f32x4 w = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)min(k, p.n_cls - 1) * p.C + cb * 8 + g * 4);
+                    for (int k = 0; k < NCA; ++k) {   // branch-free: class rows past n_cls re-read the last row (LDS broadcast)
+                        const f32x4 w = Wf[min(k, p.n_cls - 1) * (p.C >> 2) + cb * 2 + g];
                         lg[j][k] = dot4(o, w, lg[j][k]);
                     }
                 }
@@ -304,13 +344,14 @@ int launch_creff(const CreffParams &p, hipStream_t st) {
     constexpr int R = KS / 2;
     constexpr size_t fl4 = (size_t)G * ((TH + 2 * R + 2) * (TW + 2 * R + 2) + PAD) + (size_t)G * ((TH + 2 * R) * (TW + 2 * R) + PAD) +
                            (size_t)G * ((TH + 2) * (TW + 2) + PAD) + 3 * 10 * G;
-    constexpr size_t smem = fl4 * sizeof(f32x4);
-    static bool attr_set = false;
-    if (!attr_set) {
+    const size_t smem = (fl4 + (NC > 0 ? (size_t)p.n_cls * (p.C >> 2) : 0)) * sizeof(f32x4);
+    if (smem > 160 * 1024) return ARSEG_EUNSUPPORTED;
+    static size_t attr_smem = 0;     // grow-only; a race only repeats the same call
+    if (smem > attr_smem) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_kernel<KS, NC, TH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_smem = smem;
     }
     dim3 grid(arseg_cdiv(p.Wp, TW), arseg_cdiv(p.Hp, TH), p.N);
     hipLaunchKernelGGL((creff_kernel<KS, NC, TH>), grid, dim3(16 * TH), smem, st, p);

@@ -39,20 +39,22 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------ adaptive avg pool / global mean / global max
-// block = (bin, 64-channel chunk, n); 256 threads = 16 pixel lanes x 16 channel vectors; LDS tree over pixel lanes.
+// block = (bin, 16-channel chunk, n); 256 threads = 64 pixel lanes x 4 channel vectors; fixed-order LDS tree over the
+// pixel lanes (deterministic).  Small chunks keep many blocks in flight for the whole-image bins (1x1 pyramid level,
+// global mean / max), which are pure streaming reads.
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
-                                                            int H, int W, int C, int oh, int ow) {
-    __shared__ f32x4 red[16][17];
+                                                            int out_ld, int H, int W, int C, int oh, int ow) {
+    __shared__ f32x4 red[64][5];
     const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
     const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
     const int x0 = (bx * W) / ow, x1 = ((bx + 1) * W + ow - 1) / ow;
-    const int cv = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.y * 64 + cv * 4;
+    const int cv = threadIdx.x & 3, pl = threadIdx.x >> 2;
+    const int c = blockIdx.y * 16 + cv * 4;
     const int ww = x1 - x0, cnt = (y1 - y0) * ww;
     f32x4 acc = IS_MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        for (int i = pl; i < cnt; i += 16) {
+        for (int i = pl; i < cnt; i += 64) {
             const int yy = y0 + i / ww, xx = x0 + i % ww;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)n * H + yy) * W + xx) * in_ld + c);
             if (IS_MAX) { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
@@ -61,15 +63,21 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restr
     }
     red[pl][cv] = acc;
     __syncthreads();
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        if (pl < s) {
+            const f32x4 o = red[pl + s][cv];
+            f32x4 t = red[pl][cv];
+            if (IS_MAX) { t[0] = fmaxf(t[0], o[0]); t[1] = fmaxf(t[1], o[1]); t[2] = fmaxf(t[2], o[2]); t[3] = fmaxf(t[3], o[3]); }
+            else t += o;
+            red[pl][cv] = t;
+        }
+        __syncthreads();
+    }
     if (pl == 0 && c < C) {
         f32x4 t = red[0][cv];
-        for (int i = 1; i < 16; ++i) {
-            const f32x4 v = red[i][cv];
-            if (IS_MAX) { t[0] = fmaxf(t[0], v[0]); t[1] = fmaxf(t[1], v[1]); t[2] = fmaxf(t[2], v[2]); t[3] = fmaxf(t[3], v[3]); }
-            else t += v;
-        }
         if (!IS_MAX) t = t / (float)cnt;
-        *reinterpret_cast<f32x4 *>(out + ((size_t)n * oh * ow + bin) * C + c) = t;
+        *reinterpret_cast<f32x4 *>(out + ((size_t)n * oh * ow + bin) * out_ld + c) = t;
     }
 }
 
@@ -306,8 +314,8 @@ extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
     ARSEG_CHECK_POS(oh); ARSEG_CHECK_POS(ow);
     if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
-    hipLaunchKernelGGL(window_reduce_kernel<false>, dim3(oh * ow, arseg_cdiv(C, 64), N), dim3(256), 0, arseg_stream(stream), in,
-                       in_ld, out, H, W, C, oh, ow);
+    hipLaunchKernelGGL(window_reduce_kernel<false>, dim3(oh * ow, arseg_cdiv(C, 16), N), dim3(256), 0, arseg_stream(stream), in,
+                       in_ld, out, C, H, W, C, oh, ow);
     return arseg_launch_status();
 }
 
@@ -315,11 +323,11 @@ extern "C" int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, i
                                        arseg_stream_t stream) {
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
     if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
-    dim3 grid(1, arseg_cdiv(C, 64), N);
+    dim3 grid(1, arseg_cdiv(C, 16), N);
     if (op == ARSEG_REDUCE_MEAN)
-        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, H, W, C, 1, 1);
+        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, H, W, C, 1, 1);
     else if (op == ARSEG_REDUCE_MAX)
-        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, H, W, C, 1, 1);
+        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, H, W, C, 1, 1);
     else return ARSEG_EINVAL;
     return arseg_launch_status();
 }

@@ -117,3 +117,21 @@ def alter_res_step_fast(lr_net, ref_p_nhwc, img, mv_q, scale=0.5):
     ref_c8 = ops.warp_mvq(ref_p_nhwc, mv_q, _lib.C8)                  # a2 + a1
     feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(img, h, w))[-1]     # a3 + phase 1
     return lr_net.phase2_c8(feat, ref_c8)                             # CReFF + head
+
+
+def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
+    """B non-keyframes in one pass (they have no dependence on each other, evaluation.py:161-193, so the LR backbone
+    and CReFF run batched: large GEMM M, one launch sequence for the whole batch).
+
+    ref_ps: sequence of B un-warped keyframe features, NHWC [Hp,Wp,C] each (frames of one GOP share theirs);
+    imgs: [B,3,H,W]; mv_qs: int16 [B,H,W,2].  Returns (logits [B,n_cls,H',W'], p C8 [B,C/8,Hp,Wp,8]).
+    """
+    lr_net = _unwrap(lr_net)
+    B, _, H, W = imgs.shape
+    h, w = _downscale_hw(H, W, scale)
+    Hp, Wp, C = ref_ps[0].shape
+    ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=imgs.device)
+    for b in range(B):                                                 # a2 + a1 per frame (each has its own MV map)
+        ops.warp_mvq(ref_ps[b].unsqueeze(0), mv_qs[b:b + 1], _lib.C8, out=ref_c8[b:b + 1])
+    feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(imgs, h, w))[-1]     # a3 + phase 1, batched
+    return lr_net.phase2_c8(feat, ref_c8)                              # CReFF + head, batched

@@ -76,3 +76,10 @@ class GopRunner:
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
         refs = self.exchange(local_refs)
         return {(g, d): self.nonkey_fn(refs[g], frames[(g, d)], mvs[(g, d)]) for (g, d) in self.plan}
+
+    def run_batched(self, keyframes, frames_stacked, mvs_stacked, batch_fn):
+        """Same schedule with this rank's non-keyframes processed as ONE batch: ``frames_stacked`` / ``mvs_stacked`` hold
+        the frames of ``self.plan`` in plan order along dim 0; ``batch_fn(refs_per_frame, frames, mvs)`` -> outputs."""
+        local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
+        refs = self.exchange(local_refs)
+        return batch_fn([refs[g] for (g, _) in self.plan], frames_stacked, mvs_stacked)

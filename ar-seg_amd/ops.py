@@ -211,15 +211,19 @@ def mv_resize(mv_q: torch.Tensor, Hp: int, Wp: int) -> torch.Tensor:
     return out
 
 
-def warp_mvq(feature_nhwc: torch.Tensor, mv_q: torch.Tensor, out_layout: int = _lib.C8) -> torch.Tensor:
-    """MV resize + warp fused: NHWC feature [N,Hp,Wp,C], int16 quarter-pel MVs [N,H,W,2] at frame resolution."""
-    _need_gpu(feature_nhwc)
+def warp_mvq(feature_nhwc: torch.Tensor, mv_q: torch.Tensor, out_layout: int = _lib.C8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """MV resize + warp fused: NHWC feature [N,Hp,Wp,C], int16 quarter-pel MVs [N,H,W,2] at frame resolution.
+    ``out``: optional contiguous destination (e.g. one frame's slot of a batched C8 buffer)."""
+    _need_gpu(feature_nhwc, out)
     _need_gpu(mv_q, dtype=torch.int16)
     feature_nhwc, mv_q = feature_nhwc.contiguous(), mv_q.contiguous()
     N, Hp, Wp, C = feature_nhwc.shape
     _, H, W, _ = mv_q.shape
     shape = (N, C // 8, Hp, Wp, 8) if out_layout == _lib.C8 else (N, Hp, Wp, C)
-    out = torch.empty(shape, dtype=torch.float32, device=feature_nhwc.device)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=feature_nhwc.device)
+    elif tuple(out.shape) != shape or not out.is_contiguous():
+        raise _lib.ArsegError(f"warp_mvq out must be contiguous with shape {shape}")
     _launch("warp_mvq", _lib.load().arseg_warp_mvq_fwd, _ptr(feature_nhwc), _ptr(mv_q), _ptr(out), N, C, Hp, Wp, H, W, out_layout, _stream(),
             nbytes=N * (2 * 4 * C * Hp * Wp + 4 * H * W))
     return out
@@ -239,6 +243,11 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
     _, hp, wp, C2 = lr_nhwc.shape
     if C2 != C:
         raise _lib.ArsegError(f"channel mismatch: hr has {C}, lr has {C2}")
+    if N > 1 and N * C * Hp * Wp * 4 >= (1 << 31):          # the kernel addresses p_out with 32-bit buffer offsets
+        h = N // 2
+        a = creff(hr_c8[:h], lr_nhwc[:h], attn, head, log_softmax, kH, kW)
+        b = creff(hr_c8[h:], lr_nhwc[h:], attn, head, log_softmax, kH, kW)
+        return torch.cat([a[0], b[0]]), (None if a[1] is None else torch.cat([a[1], b[1]]))
     p_out = torch.empty_like(hr_c8)
     logits, wf, bf, n_cls = None, None, None, 0
     if head is not None:

@@ -93,15 +93,22 @@ def downscale(imgs: torch.Tensor, scale: float) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # a5-a7  localAttention pair + softmax             model/attention.py:13-53 (call sites 199-207)
 # ----------------------------------------------------------------------------------------------
+_ROWS = 16   # row strip: keeps the working set of one strip in cache (a whole 64x512x1024 plane set is 134 MB)
+
+
 def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
     """S[n,y,x,dy*kW+dx] = sum_c q[n,c,y,x] * k[n,c,y+dy-kH//2,x+dx-kW//2]; taps outside the
-    image contribute 0 (zero padding of the unfold, attention.py:56-58).  No 1/sqrt(C) scale."""
+    image contribute 0 (zero padding of the unfold, attention.py:56-58).  No 1/sqrt(C) scale.
+    Row-tiled: a naive F.unfold materialises C*kH*kW*H*W floats (6.6 GB at 64x512x1024)."""
     N, C, H, W = q.shape
     kp = F.pad(k, (kW // 2, kW // 2, kH // 2, kH // 2))
     out = q.new_empty(N, H, W, kH * kW)
-    for dy in range(kH):
-        for dx in range(kW):
-            out[..., dy * kW + dx] = (q * kp[:, :, dy:dy + H, dx:dx + W]).sum(dim=1)
+    for y0 in range(0, H, _ROWS):
+        y1 = min(H, y0 + _ROWS)
+        qs = q[:, :, y0:y1]
+        for dy in range(kH):
+            for dx in range(kW):
+                out[:, y0:y1, :, dy * kW + dx] = (qs * kp[:, :, y0 + dy:y1 + dy, dx:dx + W]).sum(dim=1)
     return out
 
 
@@ -109,10 +116,14 @@ def local_weighting(v: torch.Tensor, w: torch.Tensor, kH: int, kW: int) -> torch
     """O[n,c,y,x] = sum_i v[n,c,y+dy_i,x+dx_i] * w[n,y,x,i], zero padded (attention.py:75-85)."""
     N, C, H, W = v.shape
     vp = F.pad(v, (kW // 2, kW // 2, kH // 2, kH // 2))
-    out = torch.zeros_like(v)
-    for dy in range(kH):
-        for dx in range(kW):
-            out += vp[:, :, dy:dy + H, dx:dx + W] * w[..., dy * kW + dx].unsqueeze(1)
+    out = torch.empty_like(v)
+    for y0 in range(0, H, _ROWS):
+        y1 = min(H, y0 + _ROWS)
+        acc = torch.zeros_like(v[:, :, y0:y1])
+        for dy in range(kH):
+            for dx in range(kW):
+                acc += vp[:, :, y0 + dy:y1 + dy, dx:dx + W] * w[:, y0:y1, :, dy * kW + dx].unsqueeze(1)
+        out[:, :, y0:y1] = acc
     return out
 
 

@@ -1,0 +1,137 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol include/arseg_hip.h
+declares, the Python binding covers exactly that set, the host-side weight packer matches a numpy restatement, the
+module mirrors expose the reference's state_dict keys, and nothing silently falls back to the CPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "arseg_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(arseg_\w+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from arseg_amd import _lib
+
+    lib = _lib.load()                       # raises if ar-seg_amd/lib/libarseg_hip.so was not built
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in arseg_hip.h but not exported"
+    assert sorted(_lib.PROTOTYPES) == declared, "ctypes binding and header drifted apart"
+    assert lib.arseg_version() == 1
+    assert b"ok" in lib.arseg_status_string(0) and b"invalid" in lib.arseg_status_string(-1)
+
+
+def test_entry_points_reject_bad_arguments_without_a_gpu():
+    """Argument validation happens before any launch, so it is checkable on a CPU-only machine."""
+    from arseg_amd import _lib
+
+    lib = _lib.load()
+    null = ctypes.c_void_p(0)
+    assert lib.arseg_local_similar_fwd(null, null, null, 1, 8, 8, 8, 7, 7, null) == _lib.ARSEG_EINVAL
+    assert lib.arseg_warp_fwd(null, null, 0, null, 1, 8, 8, 8, 1, 1, null) == _lib.ARSEG_EINVAL
+    assert lib.arseg_creff_fwd(*([null] * 8), null, null, null, 0, null, 0, 1, 64, 8, 8, 4, 4, 7, 7, null) == _lib.ARSEG_EINVAL
+    d = _lib.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld, d.Cout, d.out_ld, d.res_ld = 1, 8, 8, 24, 24, 8, 8, 8
+    d.R, d.S, d.stride, d.pad, d.dil = 3, 3, 1, 1, 1
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED   # Cin=24 with 3x3
+    d.Cin = d.in_ld = 16
+    d.stride, d.pad, d.dil = 2, 4, 4
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    assert (ho.value, wo.value) == ((8 + 8 - 8 - 1) // 2 + 1, (8 + 8 - 8 - 1) // 2 + 1)
+    d.split_k = 4
+    # K = 9*16 = 144 -> 5 K-steps of 32; 4 requested slices -> 2 steps each -> 3 non-empty slices of fp32 partials
+    assert lib.arseg_conv2d_workspace_bytes(ctypes.byref(d)) == 3 * ho.value * wo.value * 8 * 4
+
+
+def test_weight_packer_host_functions():
+    from arseg_amd import _lib
+    from arseg_amd.packing import _hp
+
+    lib = _lib.load()
+    g = np.random.default_rng(0)
+    for cout, cin, R, S in ((5, 3, 7, 7), (8, 64, 3, 3), (12, 2560, 1, 1)):
+        w = g.standard_normal((cout, cin, R, S)).astype(np.float32)
+        cin_pad = (cin + 3) // 4 * 4
+        kpad = lib.arseg_packed_k(cin_pad, R, S)
+        assert kpad % 32 == 0 and kpad >= R * S * cin_pad
+        out = np.full((cout, kpad), 7.0, np.float32)
+        assert lib.arseg_pack_conv_weight_host(_hp(w), cout, cin, R, S, cin_pad, _hp(out)) == 0
+        want = np.zeros((cout, R * S, cin_pad), np.float32)
+        want[:, :, :cin] = w.transpose(0, 2, 3, 1).reshape(cout, R * S, cin)
+        assert np.array_equal(out[:, :R * S * cin_pad], want.reshape(cout, -1)) and not out[:, R * S * cin_pad:].any()
+    C = 16
+    gamma, beta, mean = (g.standard_normal(C).astype(np.float32) for _ in range(3))
+    var = g.uniform(0.5, 1.5, C).astype(np.float32)
+    cb = g.standard_normal(C).astype(np.float32)
+    sc, bi = np.empty(C, np.float32), np.empty(C, np.float32)
+    assert lib.arseg_fold_bn_host(_hp(gamma), _hp(beta), _hp(mean), _hp(var), ctypes.c_float(1e-5), _hp(cb), C, _hp(sc), _hp(bi)) == 0
+    x = g.standard_normal(C).astype(np.float32)                      # a conv output (without bias)
+    want = torch.nn.functional.batch_norm(torch.from_numpy(x + cb)[None, :, None, None], torch.from_numpy(mean), torch.from_numpy(var),
+                                          torch.from_numpy(gamma), torch.from_numpy(beta), False, 0.0, 1e-5).flatten().numpy()
+    assert np.abs(x * sc + bi - want).max() <= 1e-5
+    dw = g.standard_normal((C, 1, 3, 3)).astype(np.float32)
+    o = np.empty((9, C), np.float32)
+    assert lib.arseg_pack_dw3x3_host(_hp(dw), C, _hp(o)) == 0
+    assert np.array_equal(o, dw.reshape(C, 9).T)
+
+
+def test_module_mirrors_have_the_reference_state_dict(manifest):
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse, MyAttention, PSPNet, PSPNetWithFuse
+
+    ctors = {
+        "PSPNet": lambda: PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18"),
+        "PSPNetWithFuse": lambda: PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256,
+                                                 backend="resnet18", atten_k=7),
+        "BiSeNetV1": lambda: BiSeNetV1(n_classes=12, backend="resnet18"),
+        "BiSeNetV1WithFuse": lambda: BiSeNetV1WithFuse(n_classes=12, backend="resnet18"),
+        "MyAttention64": lambda: MyAttention(64, kW=7, kH=7),
+    }
+    for name, ctor in ctors.items():
+        m = ctor()
+        got = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+        assert got == manifest[name]["keys"], name                   # same keys, shapes and order as the reference module
+        wrapped = torch.nn.DataParallel(m)                           # checkpoints carry the 'module.' prefix (evaluation.py:41-46)
+        wrapped.load_state_dict({"module." + k: v for k, v in m.state_dict().items()})
+    b = ctors["BiSeNetV1WithFuse"]()
+    assert b.feat_conv_out is b.conv_out.conv and b.final_conv is b.conv_out.conv_out and b.out_upsample is b.conv_out.up
+
+
+def test_no_cpu_fallback():
+    from arseg_amd import _lib, ops
+    from arseg_amd.model import MyAttention, PSPNet
+    from arseg_amd.evaluation import warpFeature
+
+    with pytest.raises(_lib.ArsegError):
+        ops.local_similar(torch.zeros(1, 4, 8, 8), torch.zeros(1, 4, 8, 8), 7, 7)
+    with pytest.raises(_lib.ArsegError):
+        warpFeature(torch.zeros(1, 4, 8, 8), torch.zeros(1, 8, 8, 2))
+    with pytest.raises(_lib.ArsegError):
+        MyAttention(8, kW=7, kH=7).eval()(torch.zeros(1, 8, 8, 8), torch.zeros(1, 8, 4, 4))
+    net = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    with pytest.raises(_lib.ArsegError):                              # training mode: inference-only
+        net(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(_lib.ArsegError):                              # eval mode, CPU tensors
+        net.eval()(torch.zeros(1, 3, 32, 32))
+
+
+def test_synthetic_clip_matches_the_reference_mv_format():
+    from arseg_amd import synth
+
+    c = synth.make_clip(0, 64, 96, gop=4)
+    assert c["frames"].shape == (4, 3, 64, 96) and c["frames"].dtype == np.float32
+    mv = c["mv"]
+    assert mv.shape == (4, 64, 96, 2) and mv.dtype == np.int16
+    assert not mv[0].any() and (mv % 4 == 0).all() and np.abs(mv).max() <= 150 * 4      # integer-pel, clamped, keyframe has no motion
+    c2 = synth.make_clip(0, 64, 96, gop=4)
+    assert np.array_equal(c["frames"], c2["frames"]) and np.array_equal(mv, c2["mv"])     # seeded
