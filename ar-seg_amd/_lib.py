@@ -51,7 +51,8 @@ PROTOTYPES = {
     "arseg_fold_bn_host": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, _P, _P]),
     "arseg_pack_dw3x3_host": (c_int, [_P, c_int, _P]),
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
-    "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_psp_prior_sum_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_global_reduce_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_resize_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),
     "arseg_scale_add_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _STREAM]),

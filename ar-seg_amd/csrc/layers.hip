@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
 // global mean / max), which are pure streaming reads.
 template <bool IS_MAX>
 __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
-                                                            int out_ld, int H, int W, int C, int oh, int ow) {
+                                                            int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow) {
     __shared__ f32x4 red[64][5];
     const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
     const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restr
     if (pl == 0 && c < C) {
         f32x4 t = red[0][cv];
         if (!IS_MAX) t = t / (float)cnt;
-        *reinterpret_cast<f32x4 *>(out + ((size_t)n * oh * ow + bin) * out_ld + c) = t;
+        *reinterpret_cast<f32x4 *>(out + (size_t)n * out_n_stride + (size_t)bin * out_ld + c) = t;
     }
 }
 
@@ -135,6 +135,36 @@ __global__ __launch_bounds__(256) void resize_nchw_kernel(const float *__restric
                 ly * ((1.f - lx) * base[(size_t)y1 * Win + x0] + lx * base[(size_t)y1 * Win + x1]);
         }
         out[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------ pyramid priors: sum of bilinear upsamples
+// out[n,y,x,c] = sum_s bilinear(align_corners=False)( t[n, off_s .. off_s + size_s^2, c] reshaped [size_s,size_s] )(y,x)
+struct PriorSizes { int n; int size[4]; int off[4]; int rows; };
+
+__global__ __launch_bounds__(256) void psp_prior_sum_kernel(const float *__restrict__ t, float *__restrict__ out, int N, int H, int W,
+                                                            int C, PriorSizes ps) {
+    const int c4n = C >> 2;
+    const long long total = (long long)N * H * W * c4n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % c4n) * 4;
+        const long long pix = idx / c4n;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < ps.n; ++s) {
+            const int sz = ps.size[s];
+            const float *base = t + ((size_t)n * ps.rows + ps.off[s]) * C + c;
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(arseg_resize_scale(sz, H, false), y, false, sz, y0, y1, ly);
+            arseg_src_index(arseg_resize_scale(sz, W, false), x, false, sz, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(base + (size_t)(y0 * sz + x0) * C);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(base + (size_t)(y0 * sz + x1) * C);
+            const f32x4 cc = *reinterpret_cast<const f32x4 *>(base + (size_t)(y1 * sz + x0) * C);
+            const f32x4 d = *reinterpret_cast<const f32x4 *>(base + (size_t)(y1 * sz + x1) * C);
+            acc += (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * C + c) = acc;
     }
 }
 
@@ -309,13 +339,33 @@ extern "C" int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H,
     return arseg_launch_status();
 }
 
-extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int oh, int ow,
-                                          arseg_stream_t stream) {
+extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int out_ld, long long out_n_stride, int N, int H,
+                                          int W, int C, int oh, int ow, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
     ARSEG_CHECK_POS(oh); ARSEG_CHECK_POS(ow);
     if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
+    if (out_ld == 0) out_ld = C;
+    if (out_n_stride == 0) out_n_stride = (long long)oh * ow * out_ld;
+    if ((out_ld & 3) || out_ld < C || (out_n_stride & 3) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
     hipLaunchKernelGGL(window_reduce_kernel<false>, dim3(oh * ow, arseg_cdiv(C, 16), N), dim3(256), 0, arseg_stream(stream), in,
-                       in_ld, out, C, H, W, C, oh, ow);
+                       in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_psp_prior_sum_fwd(const float *t, float *out, int N, int H, int W, int C, int n_sizes, const int *sizes,
+                                       arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(t); ARSEG_CHECK_PTR(out); ARSEG_CHECK_PTR(sizes);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    if (n_sizes < 1 || n_sizes > 4 || (C & 3) || !ARSEG_ALIGNED16(t) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    PriorSizes ps;
+    ps.n = n_sizes; ps.rows = 0;
+    for (int i = 0; i < 4; ++i) { ps.size[i] = 1; ps.off[i] = 0; }
+    for (int i = 0; i < n_sizes; ++i) {
+        if (sizes[i] <= 0) return ARSEG_EINVAL;
+        ps.size[i] = sizes[i]; ps.off[i] = ps.rows; ps.rows += sizes[i] * sizes[i];
+    }
+    hipLaunchKernelGGL(psp_prior_sum_kernel, dim3(grid_for((long long)N * H * W * (C >> 2))), dim3(256), 0, arseg_stream(stream), t, out, N,
+                       H, W, C, ps);
     return arseg_launch_status();
 }
 
@@ -325,9 +375,9 @@ extern "C" int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, i
     if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
     dim3 grid(1, arseg_cdiv(C, 16), N);
     if (op == ARSEG_REDUCE_MEAN)
-        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, H, W, C, 1, 1);
+        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
     else if (op == ARSEG_REDUCE_MAX)
-        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, H, W, C, 1, 1);
+        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
     else return ARSEG_EINVAL;
     return arseg_launch_status();
 }

@@ -34,25 +34,34 @@ class PSPModule(HipModule):
         return nn.Sequential(prior, conv)
 
     def _pack(self, device):
-        return {"stages": [PackedConv.from_modules(st[1], device=device) for st in self.stages],
-                "bottleneck": PackedConv.from_modules(self.bottleneck, None, _lib.ACT_RELU, device=device)}
+        """The pyramid is folded at pack time.  Every op between the pooled maps and the bottleneck output is linear
+        (1x1 stage conv, bilinear upsample, the stage's slice of the 1x1 bottleneck conv) and 1x1 convs commute with
+        upsampling, so
+            bottleneck(cat(up(conv_s(pool_s f)), f)) = W_f f + sum_s up((W_s . Wconv_s) pool_s f) + b
+        with W_s the bottleneck columns of level s.  The 2560-channel concat and 80% of the bottleneck MACs disappear;
+        fp32 rounding differs from the reference's order of summation at the 1e-6 level."""
+        C, n = self.features, len(self.sizes)
+        wb = self.bottleneck.weight.detach().double().cpu().reshape(self.bottleneck.out_channels, -1)      # [1024, 2560]
+        comb = [wb[:, i * C:(i + 1) * C] @ self.stages[i][1].weight.detach().double().cpu().reshape(C, C) for i in range(n)]
+        w_prior = torch.cat(comb, dim=1).float()                                                            # [1024, n*C]
+        w_feat = wb[:, n * C:].float()
+        return {"prior": PackedConv(w_prior, None, None, act=_lib.ACT_NONE, device=device),
+                "feat": PackedConv(w_feat, self.bottleneck.bias, None, act=_lib.ACT_RELU, device=device)}
 
-    def alloc_cat(self, N, h, w, device):
-        """The 2560-channel concat buffer; the backbone writes its output straight into the last slice."""
-        C = self.features
-        cat = torch.empty((N, h, w, C * (len(self.sizes) + 1)), dtype=torch.float32, device=device)
-        return cat, cat[..., C * len(self.sizes):]
-
-    def forward_nhwc(self, cat):
+    def forward_nhwc(self, feats):
         pk = self.packed()
-        N, h, w, _ = cat.shape
-        C = self.features
-        feats = cat[..., C * len(self.sizes):]
+        N, h, w, C = feats.shape
+        n = len(self.sizes)
+        rows = sum(s * s for s in self.sizes)
+        # block-structured matrix: the rows of level i hold its pooled map in columns [i*C, (i+1)*C), zeros elsewhere
+        pooled = torch.zeros((N, rows, 1, n * C), dtype=torch.float32, device=feats.device)
+        off = 0
         for i, s in enumerate(self.sizes):
-            pooled = ops.adaptive_avgpool(feats, s, s)
-            prior = ops.conv2d(pooled, pk["stages"][i])
-            ops.resize_nhwc(prior, h, w, _lib.BILINEAR, False, out=cat[..., i * C:(i + 1) * C])     # F.upsample default
-        return ops.conv2d(cat, pk["bottleneck"])
+            ops.adaptive_avgpool(feats, s, s, out=pooled[0, off, 0, i * C:], out_ld=n * C, out_n_stride=rows * n * C)
+            off += s * s
+        t = ops.conv2d(pooled, pk["prior"])                                   # [N, rows, 1, 1024]: all levels, one launch
+        prior = ops.psp_prior_sum(t.reshape(N, rows, -1), self.sizes, h, w)   # sum_s upsample(t_s), F.upsample default mode
+        return ops.conv2d(feats, pk["feat"], residual=prior)                  # + W_f f + b, ReLU
 
 
 class PSPUpsample(HipModule):
@@ -99,10 +108,8 @@ class _PSPBase(HipModule):
     def phase1_nhwc4(self, x4):
         """The backbone on an NHWC4 frame (pspnet.py:198-217): -> (aux logits [N,n_cls], p NHWC)."""
         N, H, W, _ = x4.shape
-        h8, w8 = _stride8(H), _stride8(W)
-        cat, f_slot = self.psp.alloc_cat(N, h8, w8, x4.device)
-        _, class_f = self.feats.forward_nhwc(x4, out_x=f_slot)
-        p = self.psp.forward_nhwc(cat)          # drop_1 / drop_2: identity in eval
+        f, class_f = self.feats.forward_nhwc(x4)
+        p = self.psp.forward_nhwc(f)            # drop_1 / drop_2: identity in eval
         p = self.up_1.forward_nhwc(p)
         p = self.up_2.forward_nhwc(p)
         p = self.up_3.forward_nhwc(p)
@@ -124,12 +131,6 @@ class _PSPBase(HipModule):
         N, C, H, W = x.shape
         aux, p = self._trunk_nhwc(x)
         return self._final(p, H, W), aux, ops.as_nchw(p)
-
-
-def _stride8(n):
-    n = (n - 1) // 2 + 1      # conv 7x7 s2 p3
-    n = (n - 1) // 2 + 1      # maxpool 3x3 s2 p1
-    return (n - 1) // 2 + 1   # layer2 stride 2
 
 
 class PSPNet(_PSPBase):

@@ -330,11 +330,29 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int) -> torch.Tensor:
-    _need_gpu(x)
+def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int, out: Optional[torch.Tensor] = None, out_ld: int = 0, out_n_stride: int = 0
+                     ) -> torch.Tensor:
+    """NHWC -> [N,oh,ow,C]; or, with ``out`` (a base tensor/view whose data_ptr is the first bin of image 0), into rows of a
+    wider matrix: element (n, bin, c) at out + n*out_n_stride + bin*out_ld + c."""
+    _need_gpu(x, out)
     N, H, W, C = x.shape
-    out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
-    _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, oh, ow, _stream())
+    if out is None:
+        out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
+    _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), out_ld, out_n_stride, N, H, W, C,
+            oh, ow, _stream())
+    return out
+
+
+def psp_prior_sum(t: torch.Tensor, sizes, H: int, W: int) -> torch.Tensor:
+    """t [N, sum(s^2), C] (per-level maps after the folded 1x1 convs) -> [N,H,W,C] sum of bilinear upsamples."""
+    _need_gpu(t)
+    t = t.contiguous()
+    N, rows, C = t.shape
+    if rows != sum(s * s for s in sizes):
+        raise _lib.ArsegError("psp_prior_sum: row count does not match the pyramid sizes")
+    out = torch.empty((N, H, W, C), dtype=torch.float32, device=t.device)
+    arr = (ctypes.c_int * len(sizes))(*[int(s) for s in sizes])
+    _launch("psp_prior_sum", _lib.load().arseg_psp_prior_sum_fwd, _ptr(t), _ptr(out), N, H, W, C, len(sizes), arr, _stream())
     return out
 
 

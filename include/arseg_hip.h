@@ -144,9 +144,16 @@ int arseg_pack_dw3x3_host(const float *w, int C, float *out_host);
  * ------------------------------------------------------------------------------------------- */
 /* nn.MaxPool2d(3, stride 2, padding 1)             model/extractors.py:116, model/bisenet.py:77 */
 int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream);
-/* nn.AdaptiveAvgPool2d((oh,ow))                                            model/pspnet.py:23 */
-int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int oh, int ow,
-                               arseg_stream_t stream);
+/* nn.AdaptiveAvgPool2d((oh,ow))                                            model/pspnet.py:23
+ * out[n][bin][c] at out + n*out_n_stride + bin*out_ld + c (0 = dense defaults: out_ld = C, out_n_stride = oh*ow*C),
+ * so several pyramid levels can be pooled straight into one block-structured matrix. */
+int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int out_ld, long long out_n_stride, int N, int H, int W,
+                               int C, int oh, int ow, arseg_stream_t stream);
+/* PSPModule priors (model/pspnet.py:27-30), folded: with t[n][off_s + i][c] the per-level maps AFTER the stage conv and
+ * the level's slice of the bottleneck conv (both 1x1, i.e. linear and commuting with bilinear upsampling), this writes
+ * out[n,y,x,c] = sum_s upsample_bilinear(align_corners=False)(t_s[n])(y,x,c); off_s = sum_{j<s} sizes[j]^2 (host array). */
+int arseg_psp_prior_sum_fwd(const float *t, float *out, int N, int H, int W, int C, int n_sizes, const int *sizes_host,
+                            arseg_stream_t stream);
 /* torch.mean(x,(2,3)) / F.adaptive_max_pool2d(x,1): out [N][C]   model/bisenet.py:252,292,390; pspnet.py:94 */
 int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op,
                             arseg_stream_t stream);
