@@ -52,13 +52,13 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NBUF>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave (wave tile BM/2 x BN/2)
     constexpr int RA = BM / 32, RB = BN / 32;     // rows staged per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *As = smem;                              // [2][BM][LDS_LD]
-    float *Bs = smem + 2 * BM * LDS_LD;            // [2][BN][LDS_LD]
+    float *As = smem;                              // [NBUF][BM][LDS_LD]
+    float *Bs = smem + NBUF * BM * LDS_LD;         // [NBUF][BN][LDS_LD]
 
     // XCD-aware (bijective) remap of the linear block id: XCD x gets a contiguous chunk of tiles.
     const int nblk = p.tiles_m * p.tiles_n;
@@ -170,9 +170,15 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][kk], fb[tn][kk], acc[tm][tn], 0, 0, 0);
         }
-        if (more) store_tile(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
+        if (NBUF == 2) {
+            if (more) store_tile(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        } else {                      // single LDS buffer: half the LDS per block (more blocks per CU), two barriers per step
+            __syncthreads();
+            if (more) store_tile(0);
+            __syncthreads();
+        }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     }
 }
 
-struct Plan { int bm, bn, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
+struct Plan { int bm, bn, nbuf, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
 
 int make_plan(const arseg_conv_desc *d, Plan *pl) {
     if (!d) return ARSEG_EINVAL;
@@ -239,7 +245,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
     pl->ktiles = pl->Kpad / BK;
 
-    static const int cfg[5][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
+    static const int cfg[9][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
     // Tile / split-K choice, fitted to a brute-force sweep of this model family's layer shapes on MI355X
     // (scratch sweep recorded in DESIGN.md): aim for ~512 workgroups (2 per CU); take the largest tile that gets
     // there with a split-K factor that still leaves >= 8 K-steps per slice; shallow GEMMs (< 64 K-steps) are best
@@ -247,7 +253,8 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     const int target = 512;
     const int max_split = pl->ktiles / 8 > 0 ? (pl->ktiles / 8 > 16 ? 16 : pl->ktiles / 8) : 1;
     int bm = 64, bn = 64, nsplit = 1;
-    if (d->tile_cfg >= 1 && d->tile_cfg <= 4) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
+    pl->nbuf = (d->tile_cfg >= 1 && d->tile_cfg <= 4) ? 2 : 1;     // single LDS buffer (more blocks per CU) measured faster
+    if (d->tile_cfg >= 1 && d->tile_cfg <= 8) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
     else {
         const int order_deep[4] = {1, 4, 2, 3}, order_shallow[4] = {3, 3, 3, 3};
         const int *order = pl->ktiles >= 64 ? order_deep : order_shallow;
@@ -269,7 +276,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->tiles_m = arseg_cdiv(M, bm);
     pl->tiles_n = arseg_cdiv(d->Cout, bn);
     if (d->split_k > 0) nsplit = d->split_k;
-    else if (d->tile_cfg >= 1 && d->tile_cfg <= 4) {
+    else if (d->tile_cfg >= 1 && d->tile_cfg <= 8) {
         const long long tiles = (long long)pl->tiles_m * pl->tiles_n;
         const long long need = (target + tiles - 1) / tiles;
         nsplit = (int)(need < 1 ? 1 : (need > max_split ? max_split : need));
@@ -281,18 +288,18 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     return ARSEG_OK;
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NBUF>
 int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
-    const size_t smem = (size_t)2 * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t smem = (size_t)NBUF * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_set = false;     // idempotent; a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_f32_kernel<BM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_f32_kernel<BM, BN, NBUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.nsplit);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, NBUF>), grid, dim3(256), smem, st, p);
     return arseg_launch_status();
 }
 
@@ -344,10 +351,17 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.ktiles = pl.ktiles; p.ktiles_per_split = pl.ktiles_per_split; p.nsplit = pl.nsplit;
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
     hipStream_t hs = arseg_stream(stream);
-    if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128>(p, pl, hs);
-    else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64>(p, pl, hs);
-    else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128>(p, pl, hs);
-    else st = launch<64, 64>(p, pl, hs);
+    if (pl.nbuf == 1) {
+        if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128, 1>(p, pl, hs);
+        else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64, 1>(p, pl, hs);
+        else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128, 1>(p, pl, hs);
+        else st = launch<64, 64, 1>(p, pl, hs);
+    } else {
+        if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128, 2>(p, pl, hs);
+        else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64, 2>(p, pl, hs);
+        else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128, 2>(p, pl, hs);
+        else st = launch<64, 64, 2>(p, pl, hs);
+    }
     if (st != ARSEG_OK) return st;
     if (pl.nsplit > 1) {
         const long long total = (long long)pl.M * (d->Cout >> 2);

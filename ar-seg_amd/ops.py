@@ -10,6 +10,7 @@ Internal activation layout is NHWC: tensors of shape ``[N, H, W, C]`` (C contigu
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -284,9 +285,33 @@ def _nhwc_ld(t: torch.Tensor) -> int:
     return ld
 
 
+# Per-shape launch plans (tile shape, LDS buffering, split-K).  The library's built-in heuristic is good to ~10 %; the
+# first time a conv shape is seen on a device the candidates are timed with HIP events and the fastest is cached
+# (what MIOpen calls "find").  ARSEG_CONV_AUTOTUNE=0 keeps the heuristic.
+_conv_plans = {}
+_AUTOTUNE = os.environ.get("ARSEG_CONV_AUTOTUNE", "1") != "0"
+
+
+def _conv_candidates(ktiles: int, cout: int, m: int):
+    cands = []
+    for cfg in (5, 6, 7, 8, 1):
+        bn = 128 if cfg in (5, 8, 1) else 64
+        bm = 128 if cfg in (5, 6, 1) else 64
+        if bn == 128 and cout <= 64:
+            continue
+        if bm == 128 and m <= 64:
+            continue
+        for sk in (1, 2, 3, 4, 6, 8):
+            if sk > 1 and (ktiles // sk < 4 or cout % 4):
+                continue
+            cands.append((cfg, sk))
+    return cands
+
+
 def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
            tile_cfg: int = 0, split_k: int = 0) -> torch.Tensor:
-    """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view."""
+    """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view.
+    tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use)."""
     _need_gpu(x, residual, out)
     N, H, W, Cin = x.shape
     if Cin != pc.cin_pad:
@@ -311,11 +336,47 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
             raise _lib.ArsegError("residual shape mismatch")
         d.res_ld = _nhwc_ld(residual)
-    nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
-    ws = workspace(nbytes, x.device) if nbytes else None
-    _launch("conv2d", lib.arseg_conv2d_fwd, ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual),
-            _ptr(out), _ptr(ws), nbytes, _stream(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
+    flops = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
+
+    def launch(cfg, sk, record=True):
+        d.tile_cfg, d.split_k = cfg, sk
+        nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, x.device) if nbytes else None
+        args = (ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+        if record:
+            _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=flops)
+        else:
+            check(lib.arseg_conv2d_fwd(*args), "conv2d")
+
+    if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
+        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil)
+        plan = _conv_plans.get(key)
+        if plan is None:
+            plan = _conv_plans[key] = _tune_conv(launch, pc, N * Ho * Wo)
+        launch(*plan)
+    else:
+        launch(tile_cfg, split_k)
     return out
+
+
+def _tune_conv(launch, pc, m):
+    ktiles = (pc.R * pc.S * pc.cin_pad + 31) // 32
+    best, best_t = (0, 0), float("inf")
+    for cfg, sk in [(0, 0)] + _conv_candidates(ktiles, pc.cout, m):
+        try:
+            launch(cfg, sk, record=False)                          # warm (also sizes the workspace)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(3):
+                launch(cfg, sk, record=False)
+            e.record()
+            e.synchronize()
+            t = s.elapsed_time(e)
+        except _lib.ArsegError:
+            continue
+        if t < best_t:
+            best, best_t = (cfg, sk), t
+    return best
 
 
 # ----------------------------------------------------------------------------------------------

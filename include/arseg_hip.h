@@ -118,7 +118,8 @@ typedef struct arseg_conv_desc {
     int R, S, stride, pad, dil;
     int act;           /* enum arseg_act */
     float prelu_slope; /* single shared slope (nn.PReLU() default, model/pspnet.py:40) */
-    int tile_cfg;      /* 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 64x128 */
+    int tile_cfg;      /* 0 auto; 1..4 = 128x128, 128x64, 64x64, 64x128 with a double-buffered LDS tile; 5..8 = the same
+                          tiles single-buffered (half the LDS, more workgroups per CU) */
     int split_k;       /* 0 auto, >= 1 explicit */
 } arseg_conv_desc;
 
