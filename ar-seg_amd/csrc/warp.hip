@@ -123,20 +123,33 @@ __global__ __launch_bounds__(256) void mv_resize_kernel(const int16_t *__restric
     }
 }
 
+// grid = (ceil(Wp/16), Hp, N); a block covers 16 pixels of one row, 16 lanes per pixel walk the channel vectors:
+// no 64-bit index division, the four taps of a pixel are read as whole contiguous pixels (C*4 bytes each).
 __global__ __launch_bounds__(256) void warp_mvq_nhwc_kernel(const float *__restrict__ feat, const int16_t *__restrict__ mv,
                                                             float *__restrict__ out, int N, int C, int Hp, int Wp, int H, int W, int c8) {
-    const int c4n = C >> 2;
-    const long long total = (long long)N * Hp * Wp * c4n;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(idx % c4n) * 4;
-        const long long pix = idx / c4n;
-        const int x = (int)(pix % Wp), y = (int)((pix / Wp) % Hp), n = (int)(pix / ((long long)Wp * Hp));
+    const int sub = threadIdx.x & 15, y = blockIdx.y, n = blockIdx.z;
+    const int x = min(blockIdx.x * 16 + (int)(threadIdx.x >> 4), Wp - 1);      // clamped: surplus lanes redo the last pixel
+    // the fp64 coordinate arithmetic (two divisions) is done by one lane per pixel and broadcast to its 16 lanes
+    float gx = 0.f, gy = 0.f;
+    if (sub == 0) {
         double fx, fy;
-        mv_at(mv + (size_t)n * H * W * 2, H, W, Hp, Wp, y, x, fx, fy);
-        float gx, gy;
+        if (Hp == H && Wp == W) {              // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
+            const int16_t *m = mv + ((size_t)n * H * W + (size_t)y * W + x) * 2;
+            fx = (double)m[0] / 4.0; fy = (double)m[1] / 4.0;
+        } else {
+            mv_at(mv + (size_t)n * H * W * 2, H, W, Hp, Wp, y, x, fx, fy);
+        }
         norm_grid<double>(x, y, fx, fy, Hp, Wp, gx, gy);
-        const Taps t = make_taps(gx, gy, Hp, Wp);
-        *reinterpret_cast<f32x4 *>(out + out_addr(pix, c, C, (long long)Hp * Wp, c8)) = gather4(feat + (size_t)n * Hp * Wp * C, t, Wp, C, c);
+    }
+    gx = __shfl(gx, 0, 16);
+    gy = __shfl(gy, 0, 16);
+    const Taps t = make_taps(gx, gy, Hp, Wp);
+    const float *img = feat + (size_t)n * Hp * Wp * C;
+    const int hw = Hp * Wp, pix = y * Wp + x;
+    for (int c = sub * 4; c < C; c += 64) {
+        const f32x4 v = gather4(img, t, Wp, C, c);
+        const size_t o = c8 ? ((((size_t)n * (C >> 3) + (c >> 3)) * hw + pix) * 8 + (c & 4)) : (((size_t)n * hw + pix) * C + c);
+        *reinterpret_cast<f32x4 *>(out + o) = v;        // (duplicate lanes of a clamped pixel store identical values)
     }
 }
 
@@ -190,7 +203,8 @@ extern "C" int arseg_warp_mvq_fwd(const float *feature, const int16_t *mv_q, flo
     if ((C & 3) || !ARSEG_ALIGNED16(feature) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
     if (out_layout != ARSEG_NHWC && out_layout != ARSEG_C8) return ARSEG_EINVAL;
     if (out_layout == ARSEG_C8 && (C & 7)) return ARSEG_EINVAL;
-    hipLaunchKernelGGL(warp_mvq_nhwc_kernel, dim3(grid_for((long long)N * Hp * Wp * (C >> 2))), dim3(256), 0,
-                       arseg_stream(stream), feature, mv_q, out, N, C, Hp, Wp, H, W, out_layout == ARSEG_C8 ? 1 : 0);
+    if (Hp > 65535 || N > 65535) return ARSEG_EUNSUPPORTED;
+    hipLaunchKernelGGL(warp_mvq_nhwc_kernel, dim3(arseg_cdiv(Wp, 16), Hp, N), dim3(256), 0, arseg_stream(stream), feature, mv_q, out, N, C,
+                       Hp, Wp, H, W, out_layout == ARSEG_C8 ? 1 : 0);
     return arseg_launch_status();
 }
