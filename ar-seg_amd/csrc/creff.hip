@@ -90,6 +90,41 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
     const int CB = p.C >> 3;
     const int px = tx0 + lx, py0 = ty0 + 2 * yp;
 
+    // Window of the low-resolution feature this tile's upsampled pixels touch (align_corners=True source rows/cols of
+    // the tile + 1 halo), block-uniform and the same for every chunk.  Per chunk it is staged into LDS with a handful of
+    // contiguous loads and the bilinear taps are read from there; gathering the taps straight from global memory costs
+    // 16-20 scattered 16-byte loads per thread and chunk (a quarter of the kernel's time).
+    int ly_lo, ly_n, lx_lo, lx_n;
+    {
+        int a0, a1, b0, b1; float l;
+        arseg_src_index(p.sy, max(ty0 - 1, 0), true, p.hp, a0, a1, l);
+        arseg_src_index(p.sy, min(ty0 + TH, p.Hp - 1), true, p.hp, b0, b1, l);
+        ly_lo = a0; ly_n = b1 - a0 + 1;
+        arseg_src_index(p.sx, max(tx0 - 1, 0), true, p.wp, a0, a1, l);
+        arseg_src_index(p.sx, min(tx0 + TW, p.Wp - 1), true, p.wp, b0, b1, l);
+        lx_lo = a0; lx_n = b1 - a0 + 1;
+    }
+    // pass 1 parks the window in the (not yet written) K tile, pass 2 in the (no longer used) lr_up tile
+    const bool lr_lds = G * ly_n * lx_n <= (G * LPL < G * KPL ? G * LPL : G * KPL);
+    auto stage_lr = [&](f32x4 *dst, int cb, int tid) {
+        const float *src = p.lr + (size_t)n * p.hp * p.wp * p.C + cb * 8;
+        for (int i = tid; i < G * ly_n * lx_n; i += NT) {
+            const int g = i & 1, pc = i >> 1, r = pc / lx_n, c = pc - r * lx_n;
+            dst[i] = *reinterpret_cast<const f32x4 *>(src + ((size_t)(ly_lo + r) * p.wp + lx_lo + c) * p.C + g * 4);
+        }
+    };
+    // bilinear(align_corners=True) sample of the staged window at HR pixel (gy,gx), channel group g
+    auto lr_up_lds = [&](const f32x4 *win, int gy, int gx, int g) {
+        int y0, y1, x0, x1; float ly, lx2;
+        arseg_src_index(p.sy, gy, true, p.hp, y0, y1, ly);
+        arseg_src_index(p.sx, gx, true, p.wp, x0, x1, lx2);
+        ly = fminf(fmaxf(ly, 0.f), 1.f); lx2 = fminf(fmaxf(lx2, 0.f), 1.f);
+        const f32x4 *b = win + g;
+        const int r0 = (y0 - ly_lo) * lx_n - lx_lo, r1 = (y1 - ly_lo) * lx_n - lx_lo;
+        const f32x4 a = b[(r0 + x0) * 2], bb = b[(r0 + x1) * 2], cc = b[(r1 + x0) * 2], d = b[(r1 + x1) * 2];
+        return (1.f - ly) * ((1.f - lx2) * a + lx2 * bb) + ly * ((1.f - lx2) * cc + lx2 * d);
+    };
+
     // The staging loops have compile-time trip counts and are fully unrolled so that every global load of a
     // phase is in flight at once (with a `tid`-bounded loop hipcc issues them one at a time and the kernel
     // becomes latency bound at 2 waves per SIMD).
@@ -159,6 +194,11 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
         asm volatile("" : "+v"(t));
         stage_hr(cb, t);
         stage_dw(cb, t);
+        if (lr_lds) {
+            __syncthreads();             // the previous chunk's score walk is done with the K tile
+            stage_lr(Ks, cb, t);
+            __syncthreads();
+        }
         {
             constexpr int TOT = G * LH * LWD, NI = (TOT + NT - 1) / NT;
             f32x4 v[NI];
@@ -168,8 +208,9 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
                 const int g = i & 1, pc = i >> 1, r = pc / LWD, c = pc - r * LWD;
                 const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
                 const bool ok = i < TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
-                // clamped coordinates keep the gathers in range; lanes outside the image are zeroed afterwards
-                v[it] = lr_up_at(p, n, min(max(gy, 0), p.Hp - 1), min(max(gx, 0), p.Wp - 1), cb * 8 + g * 4);
+                // clamped coordinates keep the taps in range; lanes outside the image are zeroed afterwards
+                const int cy = min(max(gy, 0), p.Hp - 1), cx = min(max(gx, 0), p.Wp - 1);
+                v[it] = lr_lds ? lr_up_lds(Ks, cy, cx, g) : lr_up_at(p, n, cy, cx, cb * 8 + g * 4);
                 if (!ok) v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
@@ -259,14 +300,23 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
         asm volatile("" : "+v"(t));
         stage_hr(cb, t);
         stage_dw(cb, t);
-        // residual term for this thread's two pixels: issue the gathers now so that their latency hides under the
-        // value conv and the PV walk
+        // residual term for this thread's two pixels: from the staged window (parked in the lr_up tile, unused in this
+        // pass) after the barrier, or -- fallback -- gathered from global memory now so the latency hides under the conv
         f32x4 lrv[2][G];
+        if (lr_lds) stage_lr(Ls, cb, t);
+        else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int g = 0; g < G; ++g) lrv[j][g] = lr_up_at(p, n, min(py0 + j, p.Hp - 1), min(px, p.Wp - 1), cb * 8 + g * 4);
+                for (int g = 0; g < G; ++g) lrv[j][g] = lr_up_at(p, n, min(py0 + j, p.Hp - 1), min(px, p.Wp - 1), cb * 8 + g * 4);
+        }
         __syncthreads();
+        if (lr_lds) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < G; ++g) lrv[j][g] = lr_up_lds(Ls, min(py0 + j, p.Hp - 1), min(px, p.Wp - 1), g);
+        }
         conv_tile(2, t);
         __syncthreads();
         f32x4 a[2][G];
