@@ -89,7 +89,8 @@ _workspaces = {}
 
 
 def workspace(nbytes: int, device) -> torch.Tensor:
-    key = torch.device(device).index or 0
+    # one buffer per (device, stream): split-K partials of convs running concurrently on different streams must not alias
+    key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
