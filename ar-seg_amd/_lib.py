@@ -25,7 +25,8 @@ class ConvDesc(Structure):
     _fields_ = [("N", c_int), ("H", c_int), ("W", c_int), ("Cin", c_int), ("in_ld", c_int),
                 ("Cout", c_int), ("out_ld", c_int), ("res_ld", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
-                ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int)]
+                ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int),
+                ("batch", c_int), ("in_batch_stride", c_int64), ("w_batch_stride", c_int64), ("out_batch_stride", c_int64)]
 
 
 _P = c_void_p  # device or host pointer passed as integer
@@ -46,6 +47,10 @@ PROTOTYPES = {
     "arseg_conv_out_hw": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "arseg_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
+    "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
+    "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
+    "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),
     "arseg_packed_k": (c_int, [c_int, c_int, c_int]),
     "arseg_pack_conv_weight_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
     "arseg_fold_bn_host": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, _P, _P]),

@@ -39,8 +39,9 @@ struct ConvParams {
     int K, Kpad, M;
     int act;
     float slope;
-    int ktiles, ktiles_per_split, nsplit;
+    int ktiles, ktiles_per_split, nsplit, N_batch;
     int tiles_m, tiles_n;
+    long long in_bs, w_bs, out_bs;   // batched GEMM mode (blockIdx.y = batch index): element strides between problems
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
@@ -69,6 +70,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;   // n fastest: neighbours share A rows
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const float *__restrict__ gin = p.in + (size_t)blockIdx.y * p.in_bs;
+    const float *__restrict__ gw = p.w + (size_t)blockIdx.y * p.w_bs;
+    float *__restrict__ gout = p.out + (size_t)blockIdx.y * p.out_bs;
 
     const int tid = threadIdx.x;
     const int col4 = tid & 7;          // which 16-byte vector of the 32-float K step
@@ -112,14 +116,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
             const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4 *>(p.in + (size_t)(pbase[i] + iy * p.W + ix) * p.in_ld + c);
+            if (ok) v = *reinterpret_cast<const f32x4 *>(gin + (size_t)(pbase[i] + iy * p.W + ix) * p.in_ld + c);
             ra[i] = v;
         }
 #pragma unroll
         for (int i = 0; i < RB; ++i) {
             const int n = n0 + row0 + 32 * i;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cout) v = *reinterpret_cast<const f32x4 *>(p.w + (size_t)n * p.Kpad + k);
+            if (n < p.Cout) v = *reinterpret_cast<const f32x4 *>(gw + (size_t)n * p.Kpad + k);
             rb[i] = v;
         }
     };
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
                 if (p.nsplit == 1) {
                     v = v * sc + bi;
                     if (p.res) v += p.res[(size_t)m * p.res_ld + n];
-                    p.out[(size_t)m * p.out_ld + n] = apply_act(v, p.act, p.slope);
+                    gout[(size_t)m * p.out_ld + n] = apply_act(v, p.act, p.slope);
                 } else {
                     p.ws[((size_t)blockIdx.z * p.M + m) * p.Cout + n] = v;
                 }
@@ -250,7 +254,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     // (scratch sweep recorded in DESIGN.md): aim for ~512 workgroups (2 per CU); take the largest tile that gets
     // there with a split-K factor that still leaves >= 8 K-steps per slice; shallow GEMMs (< 64 K-steps) are best
     // served by 64x64 tiles.
-    const int target = 512;
+    const int target = d->batch > 1 ? (512 + d->batch - 1) / d->batch : 512;
     const int max_split = pl->ktiles / 8 > 0 ? (pl->ktiles / 8 > 16 ? 16 : pl->ktiles / 8) : 1;
     int bm = 64, bn = 64, nsplit = 1;
     pl->nbuf = (d->tile_cfg >= 1 && d->tile_cfg <= 4) ? 2 : 1;     // single LDS buffer (more blocks per CU) measured faster
@@ -283,6 +287,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     }
     if (nsplit > pl->ktiles) nsplit = pl->ktiles;
     if (nsplit > 1 && (d->Cout & 3)) nsplit = 1;   // the reduce kernel is 4-wide
+    if (d->batch > 1) nsplit = 1;                   // batched GEMMs bring their own parallelism
     pl->ktiles_per_split = arseg_cdiv(pl->ktiles, nsplit);
     pl->nsplit = arseg_cdiv(pl->ktiles, pl->ktiles_per_split);
     return ARSEG_OK;
@@ -298,7 +303,7 @@ int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    dim3 grid(pl.tiles_m * pl.tiles_n, 1, pl.nsplit);
+    dim3 grid(pl.tiles_m * pl.tiles_n, p.in_bs || p.w_bs || p.out_bs ? p.N_batch : 1, pl.nsplit);
     hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, NBUF>), grid, dim3(256), smem, st, p);
     return arseg_launch_status();
 }
@@ -350,6 +355,10 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.act = d->act; p.slope = d->prelu_slope;
     p.ktiles = pl.ktiles; p.ktiles_per_split = pl.ktiles_per_split; p.nsplit = pl.nsplit;
     p.tiles_m = pl.tiles_m; p.tiles_n = pl.tiles_n;
+    p.N_batch = d->batch > 1 ? d->batch : 1;
+    p.in_bs = d->batch > 1 ? d->in_batch_stride : 0; p.w_bs = d->batch > 1 ? d->w_batch_stride : 0;
+    p.out_bs = d->batch > 1 ? d->out_batch_stride : 0;
+    if (d->batch > 1 && (residual || d->batch > 65535 || (d->in_batch_stride & 3) || (d->w_batch_stride & 3))) return ARSEG_EINVAL;
     hipStream_t hs = arseg_stream(stream);
     if (pl.nbuf == 1) {
         if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128, 1>(p, pl, hs);

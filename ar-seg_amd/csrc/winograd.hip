@@ -1,0 +1,198 @@
+// Winograd F(4x4, 3x3) transforms for the 3x3 stride-1 convolutions of the backbones (pad == dilation, any dilation).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      (Lavin & Gray, "Fast Algorithms for Convolutional Neural Networks")
+//
+// One 6x6 input patch yields a 4x4 output tile with 36 multiplies per (cin,cout) pair instead of 144: the 36 element-wise
+// products over all tiles are 36 independent [T x Cin] x [Cin x Cout] GEMMs, which run on the fp32-MFMA implicit-GEMM
+// kernel in batched mode (conv_igemm.hip).  This file holds the two memory-bound transforms around them and the host-side
+// weight transform.  Dilated convs (layer3/4 of the dilated ResNet, model/extractors.py:139-142) are handled exactly by
+// the polyphase view: a dilation-d conv is d*d independent dense 3x3 convs on the sub-images {(y,x): y%d==sy, x%d==sx}.
+//
+// Layouts: V = [36][T][C], M = [36][T][Cout], T = N*d*d*tilesY*tilesX, tile t = (((n*d+sy)*d+sx)*tilesY+ty)*tilesX+tx,
+// tilesY = ceil(ceil(H/d)/4).  Threads run along channels (coalesced 4-byte accesses, 36 registers of patch per thread).
+// fp32 throughout; the transform constants grow the rounding error to ~1e-5 relative (vs 1e-6 for the direct form).
+#include "arseg_common.h"
+
+namespace {
+
+struct WinoGeom { int N, H, W, d, tilesY, tilesX, T; };
+
+__host__ __device__ inline WinoGeom make_geom(int N, int H, int W, int d) {
+    WinoGeom g;
+    g.N = N; g.H = H; g.W = W; g.d = d;
+    g.tilesY = ((H + d - 1) / d + 3) / 4;
+    g.tilesX = ((W + d - 1) / d + 3) / 4;
+    g.T = N * d * d * g.tilesY * g.tilesX;
+    return g;
+}
+
+__device__ __forceinline__ void bt6(const float x[6], float r[6]) {
+    r[0] = 4.f * x[0] - 5.f * x[2] + x[4];
+    r[1] = -4.f * x[1] - 4.f * x[2] + x[3] + x[4];
+    r[2] = 4.f * x[1] - 4.f * x[2] - x[3] + x[4];
+    r[3] = -2.f * x[1] - x[2] + 2.f * x[3] + x[4];
+    r[4] = 2.f * x[1] - x[2] - 2.f * x[3] + x[4];
+    r[5] = 4.f * x[1] - 5.f * x[3] + x[5];
+}
+
+__device__ __forceinline__ void at6(const float m[6], float y[4]) {
+    y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
+    y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
+    y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
+    y[3] = m[1] - m[2] + 8.f * m[3] - 8.f * m[4] + m[5];
+}
+
+__device__ __forceinline__ void tile_origin(const WinoGeom &g, int t, int &n, int &y0, int &x0) {
+    const int tx = t % g.tilesX; t /= g.tilesX;
+    const int ty = t % g.tilesY; t /= g.tilesY;
+    const int sx = t % g.d; t /= g.d;
+    const int sy = t % g.d;
+    n = t / g.d;
+    y0 = sy + g.d * 4 * ty;     // image row of the tile's first output
+    x0 = sx + g.d * 4 * tx;
+}
+
+__global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
+                                                           WinoGeom g) {
+    const int total = g.T * C;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int t = idx / C, c = idx - t * C;
+        int n, y0, x0;
+        tile_origin(g, t, n, y0, x0);
+        const float *base = in + (size_t)n * g.H * g.W * in_ld + c;
+        float d[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int y = y0 + g.d * (i - 1);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const int x = x0 + g.d * (j - 1);
+                d[i][j] = ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) ? base[((size_t)y * g.W + x) * in_ld] : 0.f;
+            }
+        }
+        float tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {            // B^T d : transform every column
+            float col[6], r[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+            bt6(col, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {            // (B^T d) B : transform every row
+            float r[6];
+            bt6(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * g.T + t) * C + c] = r[j];
+        }
+    }
+}
+
+__device__ __forceinline__ float wino_act(float v, int act, float slope) {
+    switch (act) {
+        case ARSEG_ACT_RELU: return fmaxf(v, 0.0f);
+        case ARSEG_ACT_PRELU: return v >= 0.0f ? v : v * slope;
+        case ARSEG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+__global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restrict__ M, const float *__restrict__ scale,
+                                                            const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
+                                                            float *__restrict__ out, int out_ld, int C, int act, float slope, WinoGeom g) {
+    const int total = g.T * C;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int t = idx / C, c = idx - t * C;
+        int n, y0, x0;
+        tile_origin(g, t, n, y0, x0);
+        float m[6][6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) m[i][j] = M[((size_t)(i * 6 + j) * g.T + t) * C + c];
+        float tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {            // A^T m : columns
+            float col[6], y[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = m[i][j];
+            at6(col, y);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tmp[i][j] = y[i];
+        }
+        const float sc = scale ? scale[c] : 1.f, bi = bias ? bias[c] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {            // (A^T m) A : rows, then the conv epilogue
+            float y[4];
+            at6(tmp[i], y);
+            const int oy = y0 + g.d * i;
+            if (oy >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ox = x0 + g.d * j;
+                if (ox >= g.W) continue;
+                const size_t pix = ((size_t)n * g.H + oy) * g.W + ox;
+                float v = y[j] * sc + bi;
+                if (res) v += res[pix * res_ld + c];
+                out[pix * out_ld + c] = wino_act(v, act, slope);
+            }
+        }
+    }
+}
+
+inline int grid_for(long long total) {
+    long long b = (total + 255) / 256;
+    return (int)(b > 16384 ? 16384 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" long long arseg_wino43_tiles(int N, int H, int W, int dil) {
+    if (N <= 0 || H <= 0 || W <= 0 || dil <= 0) return 0;
+    const long long t = (long long)N * dil * dil * (((H + dil - 1) / dil + 3) / 4) * (((W + dil - 1) / dil + 3) / 4);
+    return t;
+}
+
+extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(V); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(dil);
+    if (in_ld < C) return ARSEG_EINVAL;
+    const long long T = arseg_wino43_tiles(N, H, W, dil);
+    if (T * C >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
+    const WinoGeom g = make_geom(N, H, W, dil);
+    hipLaunchKernelGGL(wino43_input_kernel, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
+                                       int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(M); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Cout); ARSEG_CHECK_POS(dil);
+    if (out_ld < Cout || (residual && res_ld < Cout)) return ARSEG_EINVAL;
+    const long long T = arseg_wino43_tiles(N, H, W, dil);
+    if (T * Cout >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
+    const WinoGeom g = make_geom(N, H, W, dil);
+    hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for((long long)g.T * Cout)), dim3(256), 0, arseg_stream(stream), M, scale, bias,
+                       residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
+    return arseg_launch_status();
+}
+
+// U[k][co][ci] = (G g G^T)[k], k = i*6 + j; computed in double, stored fp32.  out: [36][Cout][Cin].
+extern "C" int arseg_wino43_pack_weight_host(const float *w, int Cout, int Cin, float *out) {
+    if (!w || !out || Cout <= 0 || Cin <= 0) return ARSEG_EINVAL;
+    static const double G[6][3] = {{1.0 / 4, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float *g = w + ((size_t)co * Cin + ci) * 9;
+            double tmp[6][3];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) tmp[i][j] = G[i][0] * g[0 * 3 + j] + G[i][1] * g[1 * 3 + j] + G[i][2] * g[2 * 3 + j];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) {
+                    const double u = tmp[i][0] * G[j][0] + tmp[i][1] * G[j][1] + tmp[i][2] * G[j][2];
+                    out[((size_t)(i * 6 + j) * Cout + co) * Cin + ci] = (float)u;
+                }
+        }
+    return ARSEG_OK;
+}

@@ -349,15 +349,81 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         else:
             check(lib.arseg_conv2d_fwd(*args), "conv2d")
 
+    def launch_wino(record=True):
+        _conv_wino(x, pc, residual, out, N, H, W, record)
+
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
         key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil)
         plan = _conv_plans.get(key)
         if plan is None:
-            plan = _conv_plans[key] = _tune_conv(launch, pc, N * Ho * Wo)
-        launch(*plan)
+            plan = _tune_conv(launch, pc, N * Ho * Wo)
+            if getattr(pc, "wino_u", None) is not None and _WINOGRAD:
+                t_direct = _time(lambda: launch(*plan, record=False))
+                launch_wino(record=False)                       # tunes the batched GEMM underneath
+                if _time(lambda: launch_wino(record=False)) < t_direct:
+                    plan = "wino"
+            _conv_plans[key] = plan
+        if plan == "wino":
+            launch_wino()
+        else:
+            launch(*plan)
     else:
         launch(tile_cfg, split_k)
     return out
+
+
+_WINOGRAD = os.environ.get("ARSEG_CONV_WINOGRAD", "1") != "0"
+
+
+def _time(fn, reps=3):
+    fn()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    e.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def _conv_wino(x, pc, residual, out, N, H, W, record=True):
+    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs on the MFMA kernel -> output transform."""
+    lib = _lib.load()
+    Cin, Cout, dil = pc.cin_pad, pc.cout, pc.dil
+    T = lib.arseg_wino43_tiles(N, H, W, dil)
+    V = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)
+    M = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
+    la = _launch if record else (lambda name, fn, *a, **k: check(fn(*a), name))
+    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, _stream())
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld = 1, T, 1, Cin, Cin
+    d.Cout, d.out_ld, d.res_ld = Cout, Cout, Cout
+    d.R, d.S, d.stride, d.pad, d.dil = 1, 1, 1, 0, 1
+    d.act, d.prelu_slope = _lib.ACT_NONE, 0.0
+    d.batch, d.in_batch_stride, d.w_batch_stride, d.out_batch_stride = 36, T * Cin, Cout * Cin, T * Cout
+    key = ("wino_gemm", x.device.index, T, Cin, Cout)
+    plan = _conv_plans.get(key)
+
+    def gemm(cfg, rec):
+        d.tile_cfg, d.split_k = cfg, 1
+        args = (ctypes.byref(d), _ptr(V), _ptr(pc.wino_u), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
+        if rec:
+            _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=2 * 36 * T * Cin * Cout)
+        else:
+            check(lib.arseg_conv2d_fwd(*args), "conv2d(batched)")
+
+    if plan is None:
+        best, best_t = 0, float("inf")
+        for cfg in (0, 5, 6, 7, 8, 1):
+            if cfg in (5, 8, 1) and Cout <= 64:
+                continue
+            t = _time(lambda: gemm(cfg, False))
+            if t < best_t:
+                best, best_t = cfg, t
+        plan = _conv_plans[key] = best
+    gemm(plan, record)
+    la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual),
+       _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, _stream())
 
 
 def _tune_conv(launch, pc, m):

@@ -44,6 +44,12 @@ class PackedConv:
         packed = np.empty((cout, kpad), dtype=np.float32)
         check(lib.arseg_pack_conv_weight_host(_hp(w), cout, cin, R, S, self.cin_pad, _hp(packed)), "pack_conv_weight")
         self.w = torch.from_numpy(packed).to(device)
+        # Winograd F(4x4,3x3) weights for the convs it applies to (3x3, stride 1, pad == dilation, wide enough channels)
+        self.wino_u = None
+        if R == 3 and S == 3 and self.stride == 1 and self.pad == self.dil and cin % 32 == 0 and cin >= 64 and cout % 4 == 0:
+            u = np.empty((36, cout, cin), dtype=np.float32)
+            check(lib.arseg_wino43_pack_weight_host(_hp(w), cout, cin, _hp(u)), "wino43_pack_weight")
+            self.wino_u = torch.from_numpy(u).to(device)
         cb = None if conv_bias is None else _np(conv_bias)
         if bn is not None:
             gamma, beta, mean, var = (_np(t) for t in bn)

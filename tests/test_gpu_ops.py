@@ -381,3 +381,29 @@ def test_argmax_confusion(dev, h, w, H, W):
     assert float((got_h.cpu().float() - hist).abs().sum()) <= 4
     got_p2, got_h2 = ops.argmax_confusion(logits.to(dev), label.to(dev), H, W, hist=got_h.clone())
     assert torch.equal(got_h2, 2 * got_h)                              # accumulates, deterministic
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil,act,use_res", [(2, 19, 26, 64, 64, 1, "relu", True), (1, 32, 64, 128, 96, 2, "prelu", False),
+                                                           (1, 17, 33, 256, 64, 4, "none", True), (3, 8, 8, 64, 128, 1, "relu", False)])
+def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res):
+    """Winograd F(4x4,3x3) path (incl. the polyphase handling of dilation and ragged tiles) against F.conv2d."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(77))
+    x = rnd(70, N, Cin, H, W)
+    w = rnd(71, Cout, Cin, 3, 3, scale=float(np.sqrt(2.0 / (Cin * 9))))
+    bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(72, Cout, scale=0.1), rnd(73, Cout, scale=0.1),
+          t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    acts = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "prelu": _lib.ACT_PRELU}
+    pc = PackedConv(w, None, bn, 1, dil, dil, acts[act], 0.2, dev)
+    assert pc.wino_u is not None
+    res = rnd(74, N, Cout, H, W) if use_res else None
+    want = _conv_ref(x, w, None, bn, 1, dil, dil, act, 0.2, res)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty((N, H, W, Cout), device=dev)
+    ops._conv_wino(xd, pc, rd, out, N, H, W)
+    assert maxdiff(out.permute(0, 3, 1, 2), want) <= 2e-4
+    direct = ops.conv2d(xd, pc, residual=rd, tile_cfg=7, split_k=1)
+    assert maxdiff(direct, out) <= 2e-4
