@@ -26,7 +26,8 @@ __host__ __device__ inline WinoGeom make_geom(int N, int H, int W, int d) {
     return g;
 }
 
-__device__ __forceinline__ void bt6(const float x[6], float r[6]) {
+template <typename F>
+__device__ __forceinline__ void bt6(const F x[6], F r[6]) {
     r[0] = 4.f * x[0] - 5.f * x[2] + x[4];
     r[1] = -4.f * x[1] - 4.f * x[2] + x[3] + x[4];
     r[2] = 4.f * x[1] - 4.f * x[2] - x[3] + x[4];
@@ -35,7 +36,8 @@ __device__ __forceinline__ void bt6(const float x[6], float r[6]) {
     r[5] = 4.f * x[1] - 5.f * x[3] + x[5];
 }
 
-__device__ __forceinline__ void at6(const float m[6], float y[4]) {
+template <typename F>
+__device__ __forceinline__ void at6(const F m[6], F y[4]) {
     y[0] = m[0] + m[1] + m[2] + m[3] + m[4];
     y[1] = m[1] - m[2] + 2.f * m[3] - 2.f * m[4];
     y[2] = m[1] + m[2] + 4.f * m[3] + 4.f * m[4];
@@ -52,28 +54,34 @@ __device__ __forceinline__ void tile_origin(const WinoGeom &g, int t, int &n, in
     x0 = sx + g.d * 4 * tx;
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// F = float (any C) or f32x2 (C even, 8-byte aligned rows): channels per thread
+template <typename F>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
                                                            WinoGeom g) {
-    const int total = g.T * C;
+    constexpr int VW = sizeof(F) / sizeof(float);
+    const int Cv = C / VW, total = g.T * Cv;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int t = idx / C, c = idx - t * C;
+        const int t = idx / Cv, c = (idx - t * Cv) * VW;
         int n, y0, x0;
         tile_origin(g, t, n, y0, x0);
         const float *base = in + (size_t)n * g.H * g.W * in_ld + c;
-        float d[6][6];
+        F d[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int y = y0 + g.d * (i - 1);
 #pragma unroll
             for (int j = 0; j < 6; ++j) {
                 const int x = x0 + g.d * (j - 1);
-                d[i][j] = ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) ? base[((size_t)y * g.W + x) * in_ld] : 0.f;
+                d[i][j] = F(0.f);
+                if ((unsigned)y < (unsigned)g.H && (unsigned)x < (unsigned)g.W) d[i][j] = *reinterpret_cast<const F *>(base + ((size_t)y * g.W + x) * in_ld);
             }
         }
-        float tmp[6][6];
+        F tmp[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {            // B^T d : transform every column
-            float col[6], r[6];
+            F col[6], r[6];
 #pragma unroll
             for (int i = 0; i < 6; ++i) col[i] = d[i][j];
             bt6(col, r);
@@ -82,10 +90,10 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
         }
 #pragma unroll
         for (int i = 0; i < 6; ++i) {            // (B^T d) B : transform every row
-            float r[6];
+            F r[6];
             bt6(tmp[i], r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) V[((size_t)(i * 6 + j) * g.T + t) * C + c] = r[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j];
         }
     }
 }
@@ -99,33 +107,37 @@ __device__ __forceinline__ float wino_act(float v, int act, float slope) {
     }
 }
 
+template <typename F>
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restrict__ M, const float *__restrict__ scale,
                                                             const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
                                                             float *__restrict__ out, int out_ld, int C, int act, float slope, WinoGeom g) {
-    const int total = g.T * C;
+    constexpr int VW = sizeof(F) / sizeof(float);
+    const int Cv = C / VW, total = g.T * Cv;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-        const int t = idx / C, c = idx - t * C;
+        const int t = idx / Cv, c = (idx - t * Cv) * VW;
         int n, y0, x0;
         tile_origin(g, t, n, y0, x0);
-        float m[6][6];
+        F m[6][6];
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] = M[((size_t)(i * 6 + j) * g.T + t) * C + c];
-        float tmp[4][6];
+            for (int j = 0; j < 6; ++j) m[i][j] = *reinterpret_cast<const F *>(M + ((size_t)(i * 6 + j) * g.T + t) * C + c);
+        F tmp[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {            // A^T m : columns
-            float col[6], y[4];
+            F col[6], y[4];
 #pragma unroll
             for (int i = 0; i < 6; ++i) col[i] = m[i][j];
             at6(col, y);
 #pragma unroll
             for (int i = 0; i < 4; ++i) tmp[i][j] = y[i];
         }
-        const float sc = scale ? scale[c] : 1.f, bi = bias ? bias[c] : 0.f;
+        F sc = F(1.f), bi = F(0.f);
+        if (scale) sc = *reinterpret_cast<const F *>(scale + c);
+        if (bias) bi = *reinterpret_cast<const F *>(bias + c);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {            // (A^T m) A : rows, then the conv epilogue
-            float y[4];
+            F y[4];
             at6(tmp[i], y);
             const int oy = y0 + g.d * i;
             if (oy >= g.H) continue;
@@ -134,9 +146,12 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restr
                 const int ox = x0 + g.d * j;
                 if (ox >= g.W) continue;
                 const size_t pix = ((size_t)n * g.H + oy) * g.W + ox;
-                float v = y[j] * sc + bi;
-                if (res) v += res[pix * res_ld + c];
-                out[pix * out_ld + c] = wino_act(v, act, slope);
+                F v = y[j] * sc + bi;
+                if (res) v += *reinterpret_cast<const F *>(res + pix * res_ld + c);
+                float *vp = reinterpret_cast<float *>(&v);
+#pragma unroll
+                for (int e = 0; e < VW; ++e) vp[e] = wino_act(vp[e], act, slope);
+                *reinterpret_cast<F *>(out + pix * out_ld + c) = v;
             }
         }
     }
@@ -161,7 +176,10 @@ extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int 
     const long long T = arseg_wino43_tiles(N, H, W, dil);
     if (T * C >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const WinoGeom g = make_geom(N, H, W, dil);
-    hipLaunchKernelGGL(wino43_input_kernel, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+    if (!(C & 1) && !(in_ld & 1) && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(V) & 7))
+        hipLaunchKernelGGL(wino43_input_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+    else
+        hipLaunchKernelGGL(wino43_input_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
     return arseg_launch_status();
 }
 
@@ -172,8 +190,13 @@ extern "C" int arseg_wino43_output_fwd(const float *M, const float *scale, const
     const long long T = arseg_wino43_tiles(N, H, W, dil);
     if (T * Cout >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const WinoGeom g = make_geom(N, H, W, dil);
-    hipLaunchKernelGGL(wino43_output_kernel, dim3(grid_for((long long)g.T * Cout)), dim3(256), 0, arseg_stream(stream), M, scale, bias,
-                       residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
+    auto al8 = [](const void *p) { return !(reinterpret_cast<uintptr_t>(p) & 7); };
+    if (!(Cout & 1) && !(out_ld & 1) && !(res_ld & 1) && al8(M) && al8(out) && al8(scale) && al8(bias) && al8(residual))
+        hipLaunchKernelGGL(wino43_output_kernel<f32x2>, dim3(grid_for((long long)g.T * Cout / 2)), dim3(256), 0, arseg_stream(stream), M, scale,
+                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
+    else
+        hipLaunchKernelGGL(wino43_output_kernel<float>, dim3(grid_for((long long)g.T * Cout)), dim3(256), 0, arseg_stream(stream), M, scale,
+                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
     return arseg_launch_status();
 }
 

@@ -30,17 +30,30 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-H, W, GOP, SCALE, N_CLS = 512, 1024, 12, 0.5, 12
+GOP, SCALE = 12, 0.5
+# headline workload = BASELINE.json configs[1]; "bise" = configs[2] (BiSeNet-18, Cityscapes sizes) measured in fp32 --
+# the bf16 MFMA conv path that config names is not built yet, so it is an extra, not the headline.
+CONFIGS = {
+    "psp": dict(kind="psp", H=512, W=1024, n_cls=12, C=64, feat_div=1, ref_lr_gflop=116.9, ref_hr_gflop=468.2,
+                label="PSPNet-18 HR keyframe 512x1024 + 11 non-keyframes LR 0.5x (256x512) + CReFF 7x7 @512x1024"),
+    "bise": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=60.6, ref_hr_gflop=242.8,
+                 label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256"),
+}
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
-def build_nets(dev):
+def build_nets(dev, cfg):
     from arseg_amd import synth
-    from arseg_amd.model import PSPNet, PSPNetWithFuse
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse, PSPNet, PSPNetWithFuse
 
-    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18")
-    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    N_CLS = cfg["n_cls"]
+    if cfg["kind"] == "psp":
+        hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18")
+        lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    else:
+        hr = BiSeNetV1(n_classes=N_CLS, backend="resnet18")
+        lr = BiSeNetV1WithFuse(n_classes=N_CLS, backend="resnet18")
     synth.load_synth_weights(hr, 0)
     synth.load_synth_weights(lr, 1)
     sd_hr = {k: v.clone() for k, v in hr.state_dict().items()}
@@ -55,7 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the (slow) CPU oracle leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -73,7 +87,10 @@ def main():
     from arseg_amd.gop import GopRunner
 
     _lib.load()
-    hr, lr, sd_hr, sd_lr = build_nets(dev)
+    cfg = CONFIGS[args.config]
+    H, W, N_CLS = cfg["H"], cfg["W"], cfg["n_cls"]
+    mean, std = (synth.CAMVID_MEAN, synth.CAMVID_STD) if cfg["kind"] == "psp" else (synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)
+    hr, lr, sd_hr, sd_lr = build_nets(dev, cfg)
 
     # ---- synthetic batch: `world` GOPs; this rank owns keyframe `rank` and 11 round-robin non-keyframes
     def key_fn(key_img):
@@ -87,7 +104,7 @@ def main():
     clips = {}
     needed = set(runner.my_gops) | {g for g, _ in runner.plan}
     for g in sorted(needed):
-        clips[g] = synth.make_clip(g, H, W, gop=GOP)
+        clips[g] = synth.make_clip(g, H, W, gop=GOP, mean=mean, std=std)
     keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
     frames = {(g, d): torch.from_numpy(clips[g]["frames"][d:d + 1]).to(dev) for g, d in runner.plan}
     mvs = {(g, d): torch.from_numpy(clips[g]["mv"][d:d + 1]).to(dev) for g, d in runner.plan}
@@ -133,7 +150,7 @@ def main():
 
     nonkey_per_step = world * (GOP - 1)
     result = {
-        "metric": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
+        "metric": "non-keyframe frames/sec (backbone+CReFF) at 512x1024" if args.config == "psp" else "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024",
         "value": nonkey_per_step * args.steps / elapsed,
         "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -141,8 +158,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "streams": len(streams),
-        "config": {"workload": "PSPNet-18 HR keyframe 512x1024 + 11 non-keyframes LR 0.5x (256x512) + CReFF 7x7 @512x1024, "
-                               "GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32",
+        "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32",
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
         "all_frames_per_s": world * GOP * args.steps / elapsed,
@@ -163,25 +179,35 @@ def main():
         conv = nk["conv2d"]
         conv_k = ky["conv2d"]
         tf = lambda r: r["flops"] / (r["ms"] * 1e-3) / 1e12
-        # dominant kernel of the step: conv_igemm_f32 (11 LR frames + 1 HR frame)
-        tot_flops = conv["flops"] / 3 + conv_k["flops"]               # one step = one batched LR pass + one HR pass
+        # dominant kernel of the step: conv_igemm_f32 (one batched LR pass of 11 frames + one HR frame).
+        # `achieved` counts the FLOPs the MFMA kernel actually executes (Winograd F(4x4,3x3) and the folded pyramid
+        # execute fewer than the reference's direct convs) over its own time = MFMA utilisation.
+        tot_flops = conv["flops"] / 3 + conv_k["flops"]
         tot_ms = conv["ms"] / 3 + conv_k["ms"]
         n_launch = conv["launches"] / 3 + conv_k["launches"]
+        wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output")) / 3 + \
+            sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
+        ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9          # 2*MACs of every conv/linear of the reference (hook-counted)
         result["roofline"] = {
-            "kernel": "conv_igemm_f32_kernel (implicit-GEMM conv, v_mfma_f32_32x32x2_f32)",
+            "kernel": "conv_igemm_f32_kernel (implicit-GEMM / batched Winograd GEMM, v_mfma_f32_32x32x2_f32)",
             "bound": "mfma", "achieved": tot_flops / (tot_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "traffic": None,
             "per_launch": {"avg_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
-            "lr_frame_tflops": tf(conv), "hr_frame_tflops": tf(conv_k),
+            "lr_batch_tflops": tf(conv), "hr_frame_tflops": tf(conv_k),
+            "reference_direct_conv_tflops": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12,
+            "note": "achieved = FLOPs executed by the MFMA kernel / its time; reference_direct_conv_tflops = the reference's "
+                    "direct-convolution FLOP count (SURVEY 8d) / (MFMA kernel + Winograd transform time)",
         }
         cre, wrp = nk["creff"], nk["warp_mvq"]
         # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
-        stage_bytes = 4 * 64 * H * W + 4 * 64 * (H // 2) * (W // 2) + 4 * 64 * H * W + 4 * H * W + 4 * N_CLS * H * W
+        C, fd = cfg["C"], cfg["feat_div"]
+        Hp, Wp = H // fd, W // fd
+        stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * H * W
         nb = 3 * len(runner.plan)                                         # frames covered by the profiled launches
         stage_ms = (cre["ms"] + wrp["ms"]) / nb
         result["roofline_creff"] = {
-            "kernel": "warp_mvq_nhwc_kernel + creff_kernel<7,12,16> (MV warp + fused CReFF + classifier)",
+            "kernel": "warp_mvq_nhwc_kernel + creff_kernel<7,NC,TH> (MV warp + fused CReFF + classifier)",
             "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
             "algorithmic_bytes_per_frame": stage_bytes, "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
@@ -202,15 +228,18 @@ def main():
         key = torch.from_numpy(clips[g0]["frames"][0:1])
         mvq = torch.from_numpy(clips[g0]["mv"][d0:d0 + 1])
         with torch.no_grad():
-            ref_cpu = cpu_ref.pspnet_forward(sd_hr, key)[-1]                      # outside the timed sample
+            from arseg_amd.synth import resolve_aliases
+            sd_hr, sd_lr = resolve_aliases(sd_hr), resolve_aliases(sd_lr)
+            fwd = cpu_ref.pspnet_forward if cfg["kind"] == "psp" else cpu_ref.bisenet_forward
+            ref_cpu = fwd(sd_hr, key)[-1]                                         # outside the timed sample
             t1 = time.perf_counter()
-            o_out, o_p, _, _ = cpu_ref.alter_res_step("psp", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
+            o_out, o_p, _, _ = cpu_ref.alter_res_step(cfg["kind"], sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
             cpu_s = time.perf_counter() - t1
         got = outs[0:1].cpu()                                              # plan[0] is the first frame of the batch
         ref_gpu = ops.as_nchw(key_fn(keyframes[g0]).unsqueeze(0)).cpu()
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "sample": "1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same "
-                                            "512x1024 clip with the PyTorch-CPU oracle; keyframe feature precomputed outside the sample",
+                                            f"{H}x{W} clip with the PyTorch-CPU oracle; keyframe feature precomputed outside the sample",
                                   "seconds": cpu_s}
         result["parity"] = {"max_abs_err_logprobs": float((got - o_out).abs().max()),
                             "max_abs_err_keyframe_feature": float((ref_gpu - ref_cpu).abs().max()),
