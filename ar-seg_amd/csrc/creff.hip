@@ -156,22 +156,61 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
             Wd[i] = t < 9 ? *reinterpret_cast<const f32x4 *>(w + (size_t)t * p.C + c) : *reinterpret_cast<const f32x4 *>(b + c);
         }
     };
-    // K or V tile = bias + dw3x3(Hs), zero outside the image (select, no branch: the Hs halo is zero filled, so the
-    // reads are always in range); static trip count, unrolled by two so that two items' LDS reads overlap.
+    // K or V tile = bias + dw3x3(Hs), zero outside the image (select, no branch: the Hs halo is zero filled, so the reads
+    // are always in range).  A thread owns one (column, channel group) and walks down a segment of rows with a 3-row
+    // sliding window in registers: 3 LDS reads per output instead of 9, the 9 taps + bias are read once per segment
+    // (the LDS pipeline, not the VALU, is this kernel's busiest unit).
     auto conv_tile = [&](int cv, int tid) {
-        constexpr int TOT = G * KH * KWD, NI = (TOT + NT - 1) / NT;
+        constexpr int LANES = G * KWD;                       // (column, group) pairs of one tile row
+        if constexpr (NT >= LANES) {
+            constexpr int NSEG = NT / LANES, ROWS = (KH + NSEG - 1) / NSEG;
+            const int seg = tid / LANES, rem = tid - seg * LANES, g = rem / KWD, c = rem - g * KWD;
+            if (seg < NSEG) {
+                f32x4 wt[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wt[k] = Wd[(cv * 10 + k) * G + g];
+                const f32x4 bias = Wd[(cv * 10 + 9) * G + g];
+                const int rb = seg * ROWS;
+                const f32x4 *hp = Hs + g * HPL + rb * HWD + c;
+                const int gx = tx0 - R + c;
+                const bool colok = (unsigned)gx < (unsigned)p.Wp;
+                f32x4 h[3][3];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) h[dy][dx] = hp[dy * HWD + dx];
+#pragma unroll
+                for (int i = 0; i < ROWS; ++i) {
+                    const int r = rb + i;
+                    if (r < KH) {                             // (uniform per segment except in the last one)
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) h[(i + 2) % 3][dx] = hp[(i + 2) * HWD + dx];
+                        f32x4 acc = bias;
+#pragma unroll
+                        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                            for (int dx = 0; dx < 3; ++dx) acc += wt[dy * 3 + dx] * h[(i + dy) % 3][dx];
+                        const int gy = ty0 - R + r;
+                        if (!(colok && (unsigned)gy < (unsigned)p.Hp)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                        Ks[g * KPL + r * KWD + c] = acc;
+                    }
+                }
+            }
+        } else {
+            constexpr int TOT = G * KH * KWD, NI = (TOT + NT - 1) / NT;
 #pragma unroll 2
-        for (int it = 0; it < NI; ++it) {
-            const int i = min(tid + it * NT, TOT - 1);          // the surplus lanes of the last round redo the last item
-            const int g = i / (KH * KWD), pc = i - g * (KH * KWD), r = pc / KWD, c = pc - r * KWD;
-            const int gy = ty0 - R + r, gx = tx0 - R + c;
-            f32x4 acc = Wd[(cv * 10 + 9) * G + g];
+            for (int it = 0; it < NI; ++it) {
+                const int i = min(tid + it * NT, TOT - 1);          // the surplus lanes of the last round redo the last item
+                const int g = i / (KH * KWD), pc = i - g * (KH * KWD), r = pc / KWD, c = pc - r * KWD;
+                const int gy = ty0 - R + r, gx = tx0 - R + c;
+                f32x4 acc = Wd[(cv * 10 + 9) * G + g];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+                for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) acc += Wd[(cv * 10 + dy * 3 + dx) * G + g] * Hs[g * HPL + (r + dy) * HWD + c + dx];
-            if (!((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            Ks[g * KPL + pc] = acc;
+                    for (int dx = 0; dx < 3; ++dx) acc += Wd[(cv * 10 + dy * 3 + dx) * G + g] * Hs[g * HPL + (r + dy) * HWD + c + dx];
+                if (!((unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                Ks[g * KPL + pc] = acc;
+            }
         }
     };
 

@@ -13,6 +13,8 @@ checkpoints and is out of scope.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -128,6 +130,10 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
     """
     lr_net = _unwrap(lr_net)
     B, _, H, W = imgs.shape
+    sub = int(os.environ.get("ARSEG_LR_SUBBATCH", "0"))
+    if 0 < sub < B:                       # optional: bound the working set (Winograd V / M tensors) per pass
+        outs = [alter_res_batch_fast(lr_net, ref_ps[i:i + sub], imgs[i:i + sub], mv_qs[i:i + sub], scale) for i in range(0, B, sub)]
+        return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     h, w = _downscale_hw(H, W, scale)
     Hp, Wp, C = ref_ps[0].shape
     ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=imgs.device)
