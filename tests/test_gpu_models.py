@@ -183,3 +183,47 @@ def test_full_size_properties(dev, kind, H, W):
     crop_hr = ops.to_c8(hr[:, r0 - 8:r1 + 8].contiguous(), _lib.NHWC)
     pc, _ = ops.creff(crop_hr, lr_full[:, r0 - 8:r1 + 8].contiguous(), pa, None, False)
     assert maxdiff(ops.from_c8(pf, _lib.NHWC)[:, r0:r1], ops.from_c8(pc, _lib.NHWC)[:, 8:8 + (r1 - r0)]) <= 1e-5
+
+
+@pytest.mark.parametrize("kind", ["psp", "bise"])
+def test_batched_fast_path_equals_per_frame(dev, manifest, kind):
+    """The batched GOP path (all non-keyframes of a GOP in one pass, evaluation.alter_res_batch_fast) computes exactly what
+    the frame-by-frame fast path computes: frames are independent (evaluation.py:161-193)."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+
+    hr = (_psp if kind == "psp" else _bise)(manifest, dev, False)
+    lr = (_psp if kind == "psp" else _bise)(manifest, dev, True)
+    H, W = (64, 96) if kind == "psp" else (128, 256)
+    clip = synth.make_clip(5, H, W, gop=4)
+    frames = torch.from_numpy(clip["frames"]).to(dev)
+    mvs = torch.from_numpy(clip["mv"]).to(dev)
+    with torch.no_grad():
+        ref_p = ops.to_nhwc(hr(frames[0:1])[-1])[0]
+        out_b, p_b = ev.alter_res_batch_fast(lr, [ref_p] * 3, frames[1:4], mvs[1:4], 0.5)
+        for i in range(3):
+            out_i, p_i = ev.alter_res_step_fast(lr, ref_p.unsqueeze(0), frames[1 + i:2 + i], mvs[1 + i:2 + i], 0.5)
+            # same kernels, same per-frame arithmetic; only the conv launch plans (tile / split-K / Winograd) may differ with M
+            assert maxdiff(out_b[i:i + 1], out_i) <= 2e-4
+            assert maxdiff(p_b[i:i + 1], p_i) <= 2e-4
+
+
+def test_gop_runner_single_gpu(dev, manifest):
+    """GopRunner without a process group (world 1): keyframe -> exchange (no-op) -> batched non-keyframes."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.gop import GopRunner
+
+    hr, lr = _psp(manifest, dev, False), _psp(manifest, dev, True)
+    clip = synth.make_clip(6, 48, 64, gop=12)
+    frames = torch.from_numpy(clip["frames"]).to(dev)
+    mvs = torch.from_numpy(clip["mv"]).to(dev)
+    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0],
+                       lambda ref, img, mv: ev.alter_res_step_fast(lr, ref.unsqueeze(0), img, mv, 0.5)[0], n_gops=1, gop=12)
+    assert runner.plan == [(0, d) for d in range(1, 12)]
+    with torch.no_grad():
+        out = runner.run_batched({0: frames[0:1]}, frames[1:12], mvs[1:12], lambda refs, imgs, mv: ev.alter_res_batch_fast(lr, refs, imgs, mv, 0.5)[0])
+        single = runner.run({0: frames[0:1]}, {(0, d): frames[d:d + 1] for d in range(1, 12)}, {(0, d): mvs[d:d + 1] for d in range(1, 12)})
+    assert out.shape == (11, 12, 48, 64)
+    for d in range(1, 12):
+        assert maxdiff(out[d - 1:d], single[(0, d)]) <= 2e-4
