@@ -48,7 +48,7 @@ PROTOTYPES = {
     "arseg_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
     "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
-    "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
     "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),
     "arseg_packed_k": (c_int, [c_int, c_int, c_int]),

@@ -98,6 +98,70 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
     }
 }
 
+// Input transform with the x2 bilinear upsample of PSPUpsample (F.upsample default = align_corners=False,
+// model/pspnet.py:45) fused in: `in` is the LOW-resolution tensor [N,H/2,W/2,C]; the 6x6 patch of the (never
+// materialised) upsampled image is built from a 4x4 low-resolution neighbourhood.  With scale exactly 2 the source
+// offsets are the constants 0.25 / 0.75, and clamping the neighbourhood loads to the image edge reproduces ATen's
+// border handling exactly (src < 0 -> 0; i1 = min(i0+1, h-1)).  Dilation 1 only.
+template <typename F>
+__global__ __launch_bounds__(256) void wino43_input_up2_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
+                                                               WinoGeom g) {
+    constexpr int VW = sizeof(F) / sizeof(float);
+    const int Cv = C / VW, total = g.T * Cv, h = g.H >> 1, w = g.W >> 1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int t = idx / Cv, c = (idx - t * Cv) * VW;
+        int n, y0, x0;
+        tile_origin(g, t, n, y0, x0);                     // multiples of 4 (d == 1)
+        const float *base = in + (size_t)n * h * w * in_ld + c;
+        const int by = (y0 >> 1) - 1, bx = (x0 >> 1) - 1;
+        F L[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = min(max(by + i, 0), h - 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = min(max(bx + j, 0), w - 1);
+                L[i][j] = *reinterpret_cast<const F *>(base + ((size_t)yy * w + xx) * in_ld);
+            }
+        }
+        F rows[6][4];                                     // vertical interpolation: upsampled rows y0-1 .. y0+4
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int k = i >> 1;                         // rows (y0-1,y0) use L[0],L[1]; (y0+1,y0+2) L[1],L[2]; (y0+3,y0+4) L[2],L[3]
+            const float l = (i & 1) ? 0.75f : 0.25f;
+            const bool ok = (unsigned)(y0 - 1 + i) < (unsigned)g.H;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) rows[i][j] = ok ? (1.f - l) * L[k][j] + l * L[k + 1][j] : F(0.f);
+        }
+        F d[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int k = j >> 1;
+            const float l = (j & 1) ? 0.75f : 0.25f;
+            const bool ok = (unsigned)(x0 - 1 + j) < (unsigned)g.W;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d[i][j] = ok ? (1.f - l) * rows[i][k] + l * rows[i][k + 1] : F(0.f);
+        }
+        F tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            F col[6], r[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) col[i] = d[i][j];
+            bt6(col, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            F r[6];
+            bt6(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j];
+        }
+    }
+}
+
 __device__ __forceinline__ float wino_act(float v, int act, float slope) {
     switch (act) {
         case ARSEG_ACT_RELU: return fmaxf(v, 0.0f);
@@ -170,13 +234,21 @@ extern "C" long long arseg_wino43_tiles(int N, int H, int W, int dil) {
     return t;
 }
 
-extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, arseg_stream_t stream) {
+extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
+                                      arseg_stream_t stream) {
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(V); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(dil);
     if (in_ld < C) return ARSEG_EINVAL;
+    if (upsample2x && (dil != 1 || (H & 1) || (W & 1))) return ARSEG_EUNSUPPORTED;
     const long long T = arseg_wino43_tiles(N, H, W, dil);
     if (T * C >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const WinoGeom g = make_geom(N, H, W, dil);
-    if (!(C & 1) && !(in_ld & 1) && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(V) & 7))
+    const bool vec2 = !(C & 1) && !(in_ld & 1) && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(V) & 7);
+    if (upsample2x) {
+        if (vec2) hipLaunchKernelGGL(wino43_input_up2_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+        else hipLaunchKernelGGL(wino43_input_up2_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+        return arseg_launch_status();
+    }
+    if (vec2)
         hipLaunchKernelGGL(wino43_input_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
     else
         hipLaunchKernelGGL(wino43_input_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);

@@ -75,9 +75,7 @@ class PSPUpsample(HipModule):
         return PackedConv.from_modules(self.conv[0], self.conv[1], _lib.ACT_PRELU, float(self.conv[2].weight.item()), device=device)
 
     def forward_nhwc(self, x):
-        N, h, w, C = x.shape
-        up = ops.resize_nhwc(x, 2 * h, 2 * w, _lib.BILINEAR, False)
-        return ops.conv2d(up, self.packed())
+        return ops.conv2d(x, self.packed(), up2=True)       # x2 bilinear upsample (F.upsample default) + conv + BN + PReLU
 
 
 class _PSPBase(HipModule):

@@ -289,8 +289,32 @@ def _nhwc_ld(t: torch.Tensor) -> int:
 # Per-shape launch plans (tile shape, LDS buffering, split-K).  The library's built-in heuristic is good to ~10 %; the
 # first time a conv shape is seen on a device the candidates are timed with HIP events and the fastest is cached
 # (what MIOpen calls "find").  ARSEG_CONV_AUTOTUNE=0 keeps the heuristic.
-_conv_plans = {}
 _AUTOTUNE = os.environ.get("ARSEG_CONV_AUTOTUNE", "1") != "0"
+_PLAN_FILE = os.environ.get("ARSEG_CONV_PLAN_FILE")       # optional: persist tuned plans (skips the trial launches next time)
+
+
+class _PlanCache(dict):
+    """Plans keyed by shape tuples; optionally mirrored to a JSON file."""
+
+    def __init__(self):
+        super().__init__()
+        if _PLAN_FILE and os.path.exists(_PLAN_FILE):
+            import json
+
+            with open(_PLAN_FILE) as f:
+                for k, v in json.load(f).items():
+                    super().__setitem__(tuple(json.loads(k)), tuple(v) if isinstance(v, list) else v)
+
+    def __setitem__(self, key, value):
+        super().__setitem__(key, value)
+        if _PLAN_FILE:
+            import json
+
+            with open(_PLAN_FILE, "w") as f:
+                json.dump({json.dumps(list(k)): (list(v) if isinstance(v, tuple) else v) for k, v in self.items()}, f, indent=0)
+
+
+_conv_plans = _PlanCache()
 
 
 def _conv_candidates(ktiles: int, cout: int, m: int):
@@ -310,10 +334,20 @@ def _conv_candidates(ktiles: int, cout: int, m: int):
 
 
 def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           tile_cfg: int = 0, split_k: int = 0) -> torch.Tensor:
+           tile_cfg: int = 0, split_k: int = 0, up2: bool = False) -> torch.Tensor:
     """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view.
-    tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use)."""
+    tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use).
+    up2: the conv input is the x2 bilinear (align_corners=False) upsample of ``x`` (PSPUpsample, model/pspnet.py:43-46);
+    the Winograd plan applies it inside its input transform, the direct plan materialises it first."""
     _need_gpu(x, residual, out)
+    x_low = None
+    if up2:
+        x_low = x
+        n_, h_, w_, c_ = x.shape
+        if tile_cfg or split_k or not (_AUTOTUNE and _WINOGRAD and getattr(pc, "wino_u", None) is not None):
+            x, x_low = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False), None          # explicit / direct-only: materialise
+        else:
+            x = x.new_empty((n_, 2 * h_, 2 * w_, c_))          # shape carrier; filled only if the direct plan is chosen
     N, H, W, Cin = x.shape
     if Cin != pc.cin_pad:
         raise _lib.ArsegError(f"conv expects {pc.cin_pad} input channels (padded), got {Cin}")
@@ -340,6 +374,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     flops = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
 
     def launch(cfg, sk, record=True):
+        if x_low is not None:                                   # direct plan on an upsampled input: materialise it
+            resize_nhwc(x_low, H, W, _lib.BILINEAR, False, out=x)
         d.tile_cfg, d.split_k = cfg, sk
         nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
         ws = workspace(nbytes, x.device) if nbytes else None
@@ -350,10 +386,10 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
             check(lib.arseg_conv2d_fwd(*args), "conv2d")
 
     def launch_wino(record=True):
-        _conv_wino(x, pc, residual, out, N, H, W, record)
+        _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
 
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
-        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil)
+        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None)
         plan = _conv_plans.get(key)
         if plan is None:
             plan = _tune_conv(launch, pc, N * Ho * Wo)
@@ -386,15 +422,16 @@ def _time(fn, reps=3):
     return s.elapsed_time(e) / reps
 
 
-def _conv_wino(x, pc, residual, out, N, H, W, record=True):
-    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs on the MFMA kernel -> output transform."""
+def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
+    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs on the MFMA kernel -> output transform.
+    N,H,W: conv input size; with up2 ``x`` is the half-resolution tensor the input transform upsamples on the fly."""
     lib = _lib.load()
     Cin, Cout, dil = pc.cin_pad, pc.cout, pc.dil
     T = lib.arseg_wino43_tiles(N, H, W, dil)
     V = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)
     M = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
     la = _launch if record else (lambda name, fn, *a, **k: check(fn(*a), name))
-    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, _stream())
+    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, _stream())
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.in_ld = 1, T, 1, Cin, Cin
     d.Cout, d.out_ld, d.res_ld = Cout, Cout, Cout

@@ -141,7 +141,10 @@ int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const float *w_p
  * U = arseg_wino43_pack_weight_host(w OIHW) -> [36][Cout][Cin] (Cin % 32 == 0 so that it is a valid packed 1x1 weight).
  * 2.25x..4x fewer MACs than the direct form; fp32 rounding error ~1e-5 relative instead of ~1e-6. */
 long long arseg_wino43_tiles(int N, int H, int W, int dil);
-int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, arseg_stream_t stream);
+/* upsample2x != 0: `in` is the low-resolution tensor [N,H/2,W/2,C] and the x2 bilinear (align_corners=False) upsample of
+ * PSPUpsample (model/pspnet.py:45) is applied on the fly (H, W = upsampled size, even; dil == 1). */
+int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
+                           arseg_stream_t stream);
 int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
                             int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);

@@ -407,3 +407,29 @@ def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res):
     assert maxdiff(out.permute(0, 3, 1, 2), want) <= 2e-4
     direct = ops.conv2d(xd, pc, residual=rd, tile_cfg=7, split_k=1)
     assert maxdiff(direct, out) <= 2e-4
+
+
+@pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32)])
+def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout):
+    """PSPUpsample: F.upsample(x2, bilinear, align_corners=False) -> conv3x3 (+BN+PReLU), upsample fused into the Winograd
+    input transform (borders included) vs materialised + direct."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(81))
+    x = rnd(80, N, Cin, h, w)
+    wt = rnd(82, Cout, Cin, 3, 3, scale=float(np.sqrt(2.0 / (Cin * 9))))
+    b = rnd(83, Cout, scale=0.1)
+    bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(84, Cout, scale=0.1), rnd(85, Cout, scale=0.1),
+          t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    pc = PackedConv(wt, b, bn, 1, 1, 1, _lib.ACT_PRELU, 0.3, dev)
+    up = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
+    want = _conv_ref(up, wt, b, bn, 1, 1, 1, "prelu", 0.3, None)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    out = torch.empty((N, 2 * h, 2 * w, Cout), device=dev)
+    ops._conv_wino(xd, pc, None, out, N, 2 * h, 2 * w, up2=True)
+    assert maxdiff(out.permute(0, 3, 1, 2), want) <= 2e-4
+    got = ops.conv2d(xd, pc, up2=True)                      # autotuned choice
+    assert maxdiff(got.permute(0, 3, 1, 2), want) <= 2e-4
+    got2 = ops.conv2d(xd, pc, up2=True, tile_cfg=7, split_k=1)   # forced direct
+    assert maxdiff(got2.permute(0, 3, 1, 2), want) <= 2e-4
