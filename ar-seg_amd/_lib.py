@@ -18,6 +18,7 @@ NCHW, NHWC, C8 = 0, 1, 2
 FLOW_F32, FLOW_F64 = 0, 1
 NEAREST, BILINEAR = 0, 1
 REDUCE_MEAN, REDUCE_MAX = 0, 1
+MATH_F32, MATH_F16X3 = 0, 1
 
 
 class ConvDesc(Structure):
@@ -26,7 +27,8 @@ class ConvDesc(Structure):
                 ("Cout", c_int), ("out_ld", c_int), ("res_ld", c_int),
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int),
-                ("batch", c_int), ("in_batch_stride", c_int64), ("w_batch_stride", c_int64), ("out_batch_stride", c_int64)]
+                ("batch", c_int), ("in_batch_stride", c_int64), ("w_batch_stride", c_int64), ("out_batch_stride", c_int64),
+                ("math", c_int)]
 
 
 _P = c_void_p  # device or host pointer passed as integer
@@ -53,6 +55,7 @@ PROTOTYPES = {
     "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),
     "arseg_packed_k": (c_int, [c_int, c_int, c_int]),
     "arseg_pack_conv_weight_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "arseg_split_weight_f16x3_host": (c_int, [_P, c_int, c_int, _P, _P]),
     "arseg_fold_bn_host": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, _P, _P]),
     "arseg_pack_dw3x3_host": (c_int, [_P, c_int, _P]),
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),

@@ -23,9 +23,23 @@
 //                   kernel sums them in slice order (deterministic) and applies the epilogue.
 //   XCD mapping     the linear block id is remapped so that each of the 8 XCDs (private L2) gets a
 //                   contiguous run of tiles that share activation rows.
+//
+// Two arithmetic back ends share the loader / tiling / epilogue (template parameter MATH):
+//   ARSEG_MATH_F32    v_mfma_f32_32x32x2_f32 on fp32 operands (157 TF peak, the fp32 VALU rate).
+//   ARSEG_MATH_F16X3  every fp32 operand x is represented as hi + lo, two fp16 numbers (hi = x truncated to 11 significant
+//                     bits, lo = fp16(x - hi): 22 bits together), and a.b is evaluated as a_hi.b_hi + a_hi.b_lo + a_lo.b_hi
+//                     with three v_mfma_f32_32x32x16_f16 (fp32 accumulate; the dropped lo.lo term is 2^-22 relative).
+//                     16x the MFMA rate for 3x the instructions.  Weights are split (and scaled per output channel by a
+//                     power of two so that lo stays a normal fp16) once at pack time; activations stay fp32 in HBM and
+//                     are split on their way into LDS, whose row layout becomes [32 hi halves | 32 lo halves | pad].
 #include "arseg_common.h"
+#include <cmath>
+#include <cstring>
 
 namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BK = 32;
 constexpr int LDS_LD = BK + 4;
@@ -53,8 +67,22 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-template <int BM, int BN, int NBUF>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+// fp32 x4 -> (hi, lo) fp16 x4 each; hi by truncation (a mask), so x - hi is exact and both converts are exact / RTZ
+__device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo) {
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFFE000u);
+        l[j] = v[j] - h[j];
+    }
+    hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
+    hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
+    lo.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[0], l[1]));
+    lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
+}
+
+template <int BM, int BN, int NBUF, int MATH>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave (wave tile BM/2 x BN/2)
     constexpr int RA = BM / 32, RB = BN / 32;     // rows staged per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -130,7 +158,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     auto store_tile = [&](int buf) {
         float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(a + (row0 + 32 * i) * LDS_LD + col4 * 4) = ra[i];
+        for (int i = 0; i < RA; ++i) {
+            if (MATH == ARSEG_MATH_F16X3) {
+                uint2 hi, lo;
+                split_f16x3(ra[i], hi, lo);
+                float *row = a + (row0 + 32 * i) * LDS_LD;
+                *reinterpret_cast<uint2 *>(row + col4 * 2) = hi;           // halves [0,32): hi
+                *reinterpret_cast<uint2 *>(row + 16 + col4 * 2) = lo;      // halves [32,64): lo
+            } else {
+                *reinterpret_cast<f32x4 *>(a + (row0 + 32 * i) * LDS_LD + col4 * 4) = ra[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(b + (row0 + 32 * i) * LDS_LD + col4 * 4) = rb[i];
     };
@@ -139,13 +177,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
 
-    f32x16 acc[TM][TN];
+    // f16x3 with a single MFMA tile per wave: a second accumulator for the two cross terms breaks the dependent chain
+    constexpr bool DUAL = MATH == ARSEG_MATH_F16X3 && TM * TN == 1;
+    f32x16 acc[TM][TN], acc2[1];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[0][r] = 0.0f;
 
     if (kt_begin < kt_end) {
         load_tile(kt_begin);
@@ -159,6 +201,46 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         if (more) load_tile(kt + 1);
         const float *a = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
         const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+        if (MATH == ARSEG_MATH_F16X3) {
+            // lane (li, lh) holds k = 16*ks + 8*lh + 0..7 of row li: one ds_read_b128 per operand and precision half
+            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
+            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                h16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) {
+                    fah[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + ks * 8);
+                    fal[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + 16 + ks * 8);
+                }
+#pragma unroll
+                for (int t = 0; t < TN; ++t) {
+                    fbh[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + ks * 8);
+                    fbl[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + 16 + ks * 8);
+                }
+                if (DUAL) {
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[0], fbh[0], acc2[0], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbh[0], acc[0][0], 0, 0, 0);
+                    acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[0], fbl[0], acc2[0], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[tm], fbh[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbl[tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+                    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < TN; ++tn)
+                            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh[tn], acc[tm][tn], 0, 0, 0);
+                }
+            }
+        } else
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
             f32x4 fa[TM], fb[TN];
@@ -184,6 +266,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             __syncthreads();
         }
     }
+
+    if (DUAL) acc[0][0] += acc2[0];
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
@@ -239,6 +323,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
         return ARSEG_EINVAL;
     if ((d->Cin & 3) || (d->in_ld & 3) || d->in_ld < d->Cin || d->out_ld < d->Cout) return ARSEG_EINVAL;
     if (d->R * d->S > 1 && (d->Cin & (d->Cin - 1))) return ARSEG_EUNSUPPORTED;
+    if (d->math != ARSEG_MATH_F32 && d->math != ARSEG_MATH_F16X3) return ARSEG_EINVAL;
     pl->Ho = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     pl->Wo = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (pl->Ho <= 0 || pl->Wo <= 0) return ARSEG_EINVAL;
@@ -293,19 +378,33 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     return ARSEG_OK;
 }
 
-template <int BM, int BN, int NBUF>
+template <int BM, int BN, int NBUF, int MATH>
 int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
     const size_t smem = (size_t)NBUF * (BM + BN) * LDS_LD * sizeof(float);
     static bool attr_set = false;     // idempotent; a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_f32_kernel<BM, BN, NBUF>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, NBUF, MATH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, p.in_bs || p.w_bs || p.out_bs ? p.N_batch : 1, pl.nsplit);
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, NBUF>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NBUF, MATH>), grid, dim3(256), smem, st, p);
     return arseg_launch_status();
+}
+
+template <int MATH>
+int launch_math(const ConvParams &p, const Plan &pl, hipStream_t hs) {
+    if (pl.nbuf == 1) {
+        if (pl.bm == 128 && pl.bn == 128) return launch<128, 128, 1, MATH>(p, pl, hs);
+        if (pl.bm == 128 && pl.bn == 64) return launch<128, 64, 1, MATH>(p, pl, hs);
+        if (pl.bm == 64 && pl.bn == 128) return launch<64, 128, 1, MATH>(p, pl, hs);
+        return launch<64, 64, 1, MATH>(p, pl, hs);
+    }
+    if (pl.bm == 128 && pl.bn == 128) return launch<128, 128, 2, MATH>(p, pl, hs);
+    if (pl.bm == 128 && pl.bn == 64) return launch<128, 64, 2, MATH>(p, pl, hs);
+    if (pl.bm == 64 && pl.bn == 128) return launch<64, 128, 2, MATH>(p, pl, hs);
+    return launch<64, 64, 2, MATH>(p, pl, hs);
 }
 
 }  // namespace
@@ -360,17 +459,7 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.out_bs = d->batch > 1 ? d->out_batch_stride : 0;
     if (d->batch > 1 && (residual || d->batch > 65535 || (d->in_batch_stride & 3) || (d->w_batch_stride & 3))) return ARSEG_EINVAL;
     hipStream_t hs = arseg_stream(stream);
-    if (pl.nbuf == 1) {
-        if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128, 1>(p, pl, hs);
-        else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64, 1>(p, pl, hs);
-        else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128, 1>(p, pl, hs);
-        else st = launch<64, 64, 1>(p, pl, hs);
-    } else {
-        if (pl.bm == 128 && pl.bn == 128) st = launch<128, 128, 2>(p, pl, hs);
-        else if (pl.bm == 128 && pl.bn == 64) st = launch<128, 64, 2>(p, pl, hs);
-        else if (pl.bm == 64 && pl.bn == 128) st = launch<64, 128, 2>(p, pl, hs);
-        else st = launch<64, 64, 2>(p, pl, hs);
-    }
+    st = d->math == ARSEG_MATH_F16X3 ? launch_math<ARSEG_MATH_F16X3>(p, pl, hs) : launch_math<ARSEG_MATH_F32>(p, pl, hs);
     if (st != ARSEG_OK) return st;
     if (pl.nsplit > 1) {
         const long long total = (long long)pl.M * (d->Cout >> 2);
@@ -394,6 +483,63 @@ extern "C" int arseg_pack_conv_weight_host(const float *w, int Cout, int Cin, in
         for (int ci = 0; ci < Cin; ++ci)
             for (int r = 0; r < R; ++r)
                 for (int s = 0; s < S; ++s) o[(r * S + s) * Cin_pad + ci] = w[(((size_t)co * Cin + ci) * R + r) * S + s];
+    }
+    return ARSEG_OK;
+}
+
+// fp32 packed weights [Cout][Kpad] -> f16x3 operand format: per 32-k tile 32 hi halves then 32 lo halves (same bytes),
+// row co pre-multiplied by chan_mul[co] = 2^e with max|w| * 2^e in [16,32) -- exact, undone by chan_mul_inv in the epilogue
+// scale -- so that the lo halves of the significant weights are normal fp16 numbers.
+static inline uint16_t f32_to_f16_rtz(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));
+    if (e >= 31) return (uint16_t)(sign | 0x7bffu);                 // RTZ never reaches infinity
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        return (uint16_t)(sign | (man >> (14 - e)));
+    }
+    return (uint16_t)(sign | ((uint32_t)e << 10) | (man >> 13));
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const int e = (h >> 10) & 0x1f;
+    const uint32_t man = h & 0x3ffu;
+    float r;
+    if (e == 0) r = ldexpf((float)man, -24);
+    else if (e == 31) r = man ? NAN : INFINITY;
+    else r = ldexpf((float)(man | 0x400u), e - 25);
+    return sign ? -r : r;
+}
+
+extern "C" int arseg_split_weight_f16x3_host(const float *w_packed, int Cout, int Kpad, void *out_host, float *chan_mul_inv) {
+    if (!w_packed || !out_host || Cout <= 0 || Kpad <= 0 || (Kpad % BK)) return ARSEG_EINVAL;
+    uint16_t *o = reinterpret_cast<uint16_t *>(out_host);
+    for (int co = 0; co < Cout; ++co) {
+        const float *row = w_packed + (size_t)co * Kpad;
+        float mx = 0.0f;
+        for (int k = 0; k < Kpad; ++k) mx = fmaxf(mx, fabsf(row[k]));
+        int e = 0;
+        if (chan_mul_inv && mx > 0.0f && std::isfinite(mx)) {
+            int ex;
+            frexpf(mx, &ex);          // mx = f * 2^ex, f in [0.5,1)  ->  mx * 2^(5-ex) in [16,32)
+            e = 5 - ex;
+            if (e > 100) e = 100;
+            if (e < -100) e = -100;
+        }
+        if (chan_mul_inv) chan_mul_inv[co] = ldexpf(1.0f, -e);
+        for (int kt = 0; kt < Kpad / BK; ++kt)
+            for (int j = 0; j < BK; ++j) {
+                const float x = ldexpf(row[kt * BK + j], e);
+                const uint16_t hi = f32_to_f16_rtz(x);
+                const uint16_t lo = f32_to_f16_rtz(x - f16_to_f32(hi));
+                o[((size_t)co * (Kpad / BK) + kt) * 2 * BK + j] = hi;
+                o[((size_t)co * (Kpad / BK) + kt) * 2 * BK + BK + j] = lo;
+            }
     }
     return ARSEG_OK;
 }

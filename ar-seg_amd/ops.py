@@ -290,6 +290,18 @@ def _nhwc_ld(t: torch.Tensor) -> int:
 # first time a conv shape is seen on a device the candidates are timed with HIP events and the fastest is cached
 # (what MIOpen calls "find").  ARSEG_CONV_AUTOTUNE=0 keeps the heuristic.
 _AUTOTUNE = os.environ.get("ARSEG_CONV_AUTOTUNE", "1") != "0"
+# Which MFMA back end evaluates the fp32 GEMMs (include/arseg_hip.h: enum arseg_math): "f16x3" = fp32 emulated with three
+# fp16 MFMAs on hi/lo-split operands (22-bit significands, fp32 accumulate), "f32" = the fp32 MFMA.
+_MATH_NAMES = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3}
+_math = _MATH_NAMES[os.environ.get("ARSEG_CONV_MATH", "f16x3")]
+
+
+def set_conv_math(name: str) -> str:
+    """Select the conv arithmetic back end ("f32" | "f16x3") for subsequent launches; returns the previous one."""
+    global _math
+    prev = [k for k, v in _MATH_NAMES.items() if v == _math][0]
+    _math = _MATH_NAMES[name]
+    return prev
 _PLAN_FILE = os.environ.get("ARSEG_CONV_PLAN_FILE")       # optional: persist tuned plans (skips the trial launches next time)
 
 
@@ -357,6 +369,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
     d.act, d.prelu_slope = pc.act, pc.slope
     d.tile_cfg, d.split_k = tile_cfg, split_k
+    d.math = math = _math
+    w_dev, scale_dev = (pc.w_h3, pc.scale_h3) if math == _lib.MATH_F16X3 else (pc.w, pc.scale)
     d.out_ld, d.res_ld = pc.cout, pc.cout     # provisional, for the shape query
     lib = _lib.load()
     ho, wo = ctypes.c_int(), ctypes.c_int()
@@ -379,7 +393,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         d.tile_cfg, d.split_k = cfg, sk
         nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
         ws = workspace(nbytes, x.device) if nbytes else None
-        args = (ctypes.byref(d), _ptr(x), _ptr(pc.w), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+        args = (ctypes.byref(d), _ptr(x), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
         if record:
             _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=flops)
         else:
@@ -389,7 +403,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
 
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
-        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None)
+        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
         plan = _conv_plans.get(key)
         if plan is None:
             plan = _tune_conv(launch, pc, N * Ho * Wo)
@@ -438,12 +452,14 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     d.R, d.S, d.stride, d.pad, d.dil = 1, 1, 1, 0, 1
     d.act, d.prelu_slope = _lib.ACT_NONE, 0.0
     d.batch, d.in_batch_stride, d.w_batch_stride, d.out_batch_stride = 36, T * Cin, Cout * Cin, T * Cout
-    key = ("wino_gemm", x.device.index, T, Cin, Cout)
+    d.math = math = _math
+    u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math == _lib.MATH_F16X3 else (pc.wino_u, pc.scale)
+    key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
     plan = _conv_plans.get(key)
 
     def gemm(cfg, rec):
         d.tile_cfg, d.split_k = cfg, 1
-        args = (ctypes.byref(d), _ptr(V), _ptr(pc.wino_u), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
+        args = (ctypes.byref(d), _ptr(V), _ptr(u_dev), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
         if rec:
             _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=2 * 36 * T * Cin * Cout)
         else:
@@ -459,7 +475,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
                 best, best_t = cfg, t
         plan = _conv_plans[key] = best
     gemm(plan, record)
-    la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual),
+    la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual),
        _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, _stream())
 
 

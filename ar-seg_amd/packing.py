@@ -44,12 +44,23 @@ class PackedConv:
         packed = np.empty((cout, kpad), dtype=np.float32)
         check(lib.arseg_pack_conv_weight_host(_hp(w), cout, cin, R, S, self.cin_pad, _hp(packed)), "pack_conv_weight")
         self.w = torch.from_numpy(packed).to(device)
+        # the same weights in the split-fp16 operand format of ARSEG_MATH_F16X3 (+ the per-channel power-of-two factor)
+        h3 = np.empty((cout, kpad), dtype=np.float32)
+        mul_inv = np.empty(cout, dtype=np.float32)
+        check(lib.arseg_split_weight_f16x3_host(_hp(packed), cout, kpad, _hp(h3), _hp(mul_inv)), "split_weight_f16x3")
+        self.w_h3 = torch.from_numpy(h3).to(device)
         # Winograd F(4x4,3x3) weights for the convs it applies to (3x3, stride 1, pad == dilation, wide enough channels)
         self.wino_u = None
         if R == 3 and S == 3 and self.stride == 1 and self.pad == self.dil and cin % 32 == 0 and cin >= 64 and cout % 4 == 0:
             u = np.empty((36, cout, cin), dtype=np.float32)
             check(lib.arseg_wino43_pack_weight_host(_hp(w), cout, cin, _hp(u)), "wino43_pack_weight")
             self.wino_u = torch.from_numpy(u).to(device)
+            e = 5 - np.frexp(np.maximum(np.abs(u).max(axis=(0, 2)), 1e-30))[1]          # per channel, over the 36 slices
+            u_h3 = np.empty_like(u)
+            us = np.ascontiguousarray(np.ldexp(u, e[None, :, None].astype(np.int32)), dtype=np.float32)
+            check(lib.arseg_split_weight_f16x3_host(_hp(us), 36 * cout, cin, _hp(u_h3), _hp(None)), "split_weight_f16x3")
+            self.wino_u_h3 = torch.from_numpy(u_h3).to(device)
+            wino_mul_inv = np.ldexp(np.float32(1.0), -e).astype(np.float32)
         cb = None if conv_bias is None else _np(conv_bias)
         if bn is not None:
             gamma, beta, mean, var = (_np(t) for t in bn)
@@ -60,8 +71,11 @@ class PackedConv:
             self.scale = torch.from_numpy(scale).to(device)
             self.bias = torch.from_numpy(bias).to(device)
         else:
+            scale = np.ones(cout, dtype=np.float32)
             self.scale = None
             self.bias = None if cb is None else torch.from_numpy(cb).to(device)
+        self.scale_h3 = torch.from_numpy(scale * mul_inv).to(device)
+        self.wino_scale_h3 = torch.from_numpy(scale * wino_mul_inv).to(device) if self.wino_u is not None else None
 
     @staticmethod
     def from_modules(conv, bn=None, act=_lib.ACT_NONE, slope=0.0, device="cuda"):

@@ -126,7 +126,15 @@ typedef struct arseg_conv_desc {
        batch <= 1 = a single problem.  No residual and no split-K in batched mode. */
     int batch;
     long long in_batch_stride, w_batch_stride, out_batch_stride;
+    int math;          /* enum arseg_math: which MFMA back end evaluates the fp32 GEMM (selects the w_packed format too) */
 } arseg_conv_desc;
+
+/* ARSEG_MATH_F32:   v_mfma_f32_32x32x2_f32 on the fp32 operands; w_packed from arseg_pack_conv_weight_host.
+ * ARSEG_MATH_F16X3: fp32 emulated on the fp16 matrix cores: x = hi + lo (two fp16, 22 significant bits),
+ *                   a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi with fp32 accumulation (error ~2^-21 relative per product,
+ *                   operands must satisfy |x| < 65504).  w_packed from arseg_split_weight_f16x3_host, and `scale` must
+ *                   carry that function's per-channel chan_mul_inv factor. */
+enum arseg_math { ARSEG_MATH_F32 = 0, ARSEG_MATH_F16X3 = 1 };
 
 int arseg_conv_out_hw(const arseg_conv_desc *d, int *Ho, int *Wo);
 size_t arseg_conv2d_workspace_bytes(const arseg_conv_desc *d);
@@ -156,6 +164,10 @@ int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float 
  * arseg_pack_dw3x3_host: depthwise [C][1][3][3] -> [9][C]. */
 int arseg_packed_k(int Cin_pad, int R, int S);
 int arseg_pack_conv_weight_host(const float *w_oihw, int Cout, int Cin, int R, int S, int Cin_pad, float *out_host);
+/* arseg_split_weight_f16x3_host: [Cout][Kpad] fp32 (from arseg_pack_conv_weight_host / arseg_wino43_pack_weight_host rows)
+ * -> ARSEG_MATH_F16X3 operand format (same byte count: per 32-k tile 32 hi halves then 32 lo halves), each row multiplied
+ * by a power of two; chan_mul_inv[Cout] receives the inverse factors (multiply them into the epilogue scale); NULL = no scaling. */
+int arseg_split_weight_f16x3_host(const float *w_packed_host, int Cout, int Kpad, void *out_host, float *chan_mul_inv);
 int arseg_fold_bn_host(const float *gamma, const float *beta, const float *mean, const float *var, float eps,
                        const float *conv_bias, int C, float *scale_out, float *bias_out);
 int arseg_pack_dw3x3_host(const float *w, int C, float *out_host);

@@ -228,8 +228,18 @@ def _conv_ref(x, w, b, bn, stride, pad, dil, act, slope, res):
     return y
 
 
+@pytest.fixture(params=["f32", "f16x3"])
+def conv_math(request):
+    """Run a conv test under both MFMA back ends (fp32 MFMA; fp32 emulated by three fp16 MFMAs on split operands)."""
+    from arseg_amd import ops
+
+    prev = ops.set_conv_math(request.param)
+    yield request.param
+    ops.set_conv_math(prev)
+
+
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[3]}to{c[4]}k{c[5]}s{c[6]}d{c[8]}")
-def test_conv2d(dev, case):
+def test_conv2d(dev, case, conv_math):
     from arseg_amd import _lib, ops
     from arseg_amd.packing import PackedConv
 
@@ -263,7 +273,7 @@ def test_conv2d(dev, case):
         assert maxdiff(got, want) <= tol, (tile_cfg, split_k)
 
 
-def test_conv2d_channel_slices(dev):
+def test_conv2d_channel_slices(dev, conv_math):
     """in_ld / out_ld: read a channel slice of a wider NHWC buffer and write into one (zero-copy concat)."""
     from arseg_amd import _lib, ops
     from arseg_amd.packing import PackedConv
@@ -385,7 +395,7 @@ def test_argmax_confusion(dev, h, w, H, W):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,dil,act,use_res", [(2, 19, 26, 64, 64, 1, "relu", True), (1, 32, 64, 128, 96, 2, "prelu", False),
                                                            (1, 17, 33, 256, 64, 4, "none", True), (3, 8, 8, 64, 128, 1, "relu", False)])
-def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res):
+def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res, conv_math):
     """Winograd F(4x4,3x3) path (incl. the polyphase handling of dilation and ragged tiles) against F.conv2d."""
     from arseg_amd import _lib, ops
     from arseg_amd.packing import PackedConv
@@ -410,7 +420,7 @@ def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res):
 
 
 @pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32)])
-def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout):
+def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     """PSPUpsample: F.upsample(x2, bilinear, align_corners=False) -> conv3x3 (+BN+PReLU), upsample fused into the Winograd
     input transform (borders included) vs materialised + direct."""
     from arseg_amd import _lib, ops
@@ -433,3 +443,27 @@ def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout):
     assert maxdiff(got.permute(0, 3, 1, 2), want) <= 2e-4
     got2 = ops.conv2d(xd, pc, up2=True, tile_cfg=7, split_k=1)   # forced direct
     assert maxdiff(got2.permute(0, 3, 1, 2), want) <= 2e-4
+
+
+def test_conv2d_f16x3_accuracy(dev):
+    """The split-fp16 back end must stay at fp32-grade accuracy (not fp16-grade) on a deep, wide-dynamic-range GEMM:
+    K = 4608 with activations spanning 1e-3..1e2; compared against an fp64 reference, next to the fp32 MFMA back end."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(91))
+    x = t((g.standard_normal((1, 512, 12, 20)) * np.exp(g.uniform(-7, 4.6, (1, 512, 12, 20)))).astype(np.float32))
+    w = rnd(92, 128, 512, 3, 3, scale=0.02) * t(np.exp(g.uniform(-3, 3, (128, 1, 1, 1))).astype(np.float32))
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    err = {}
+    for m in ("f32", "f16x3"):
+        prev = ops.set_conv_math(m)
+        try:
+            got = ops.conv2d(xd, pc, tile_cfg=5, split_k=1).permute(0, 3, 1, 2).cpu().double()
+        finally:
+            ops.set_conv_math(prev)
+        err[m] = float((got - want).abs().max() / want.abs().max())
+    assert err["f32"] < 5e-6, err
+    assert err["f16x3"] < 5e-6 and err["f16x3"] < 2 * err["f32"], err      # measured 1.5e-6 vs 2.3e-6; plain fp16 would be ~1e-3
