@@ -40,9 +40,9 @@ namespace {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 32;
-constexpr int LDS_LD = BK + 4;
+constexpr int KALIGN = 32;       // packed K is padded to a multiple of this (one f16x3 weight tile)
 
 struct ConvParams {
     const float *in, *w, *scale, *bias, *res;
@@ -55,6 +55,8 @@ struct ConvParams {
     float slope;
     int ktiles, ktiles_per_split, nsplit, N_batch;
     int tiles_m, tiles_n;
+    int inv_S;                       // 65536/S + 1: r = (rs*inv_S) >> 16 without a division
+    unsigned in_bytes, w_bytes;      // extents for the buffer descriptors
     long long in_bs, w_bs, out_bs;   // batched GEMM mode (blockIdx.y = batch index): element strides between problems
 };
 
@@ -81,10 +83,14 @@ __device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo)
     lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
 }
 
-template <int BM, int BN, int NBUF, int MATH>
+template <int BM, int BN, int BK, int NBUF, int MATH>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    constexpr int LDS_LD = BK + 4;                // floats per LDS row (the +4 pad keeps the ds_read_b128 fragments conflict free)
+    constexpr int CPR = BK / 4;                   // 16-byte chunks per row of a K step
+    constexpr int RPP = 256 / CPR;                // rows staged per pass of the 256 threads
     constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave (wave tile BM/2 x BN/2)
-    constexpr int RA = BM / 32, RB = BN / 32;     // rows staged per thread
+    constexpr int RA = BM / RPP, RB = BN / RPP;   // rows staged per thread
+    constexpr unsigned OOB = 0x80000000u;         // beyond num_records of either buffer: the load returns zeros
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *As = smem;                              // [NBUF][BM][LDS_LD]
     float *Bs = smem + NBUF * BM * LDS_LD;         // [NBUF][BN][LDS_LD]
@@ -98,79 +104,90 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;   // n fastest: neighbours share A rows
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const float *__restrict__ gin = p.in + (size_t)blockIdx.y * p.in_bs;
-    const float *__restrict__ gw = p.w + (size_t)blockIdx.y * p.w_bs;
     float *__restrict__ gout = p.out + (size_t)blockIdx.y * p.out_bs;
+    // operands through buffer descriptors: a load whose offset is out of range returns zeros, which is how image padding,
+    // tile tails and K padding are produced without branches
+    const __amdgpu_buffer_rsrc_t a_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in + (size_t)blockIdx.y * p.in_bs), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w + (size_t)blockIdx.y * p.w_bs), 0, (int)p.w_bytes, 0x00020000);
 
     const int tid = threadIdx.x;
-    const int col4 = tid & 7;          // which 16-byte vector of the 32-float K step
-    const int row0 = tid >> 3;         // 0..31
+    const int chunk = tid & (CPR - 1);  // which 16-byte vector of the BK-float K step
+    const int row0 = tid / CPR;
 
     // decode the output pixels this thread stages (constant over the K loop)
-    int iy0[RA], ix0[RA], pbase[RA];
+    int iy0[RA], ix0[RA], rowoff[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int m = m0 + row0 + 32 * i;
+        const int m = m0 + row0 + RPP * i;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             iy0[i] = oy * p.stride - p.pad;
             ix0[i] = ox * p.stride - p.pad;
-            pbase[i] = n * p.H * p.W;
+            rowoff[i] = ((n * p.H + iy0[i]) * p.W + ix0[i]) * p.in_ld * 4 + chunk * 16;     // bytes; may be negative
         } else {
-            iy0[i] = -(1 << 28); ix0[i] = 0; pbase[i] = 0;     // every tap fails the bounds test
+            iy0[i] = -(1 << 28); ix0[i] = 0; rowoff[i] = 0;     // every tap fails the bounds test
         }
+    }
+    unsigned woff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + row0 + RPP * i;
+        woff[i] = n < p.Cout ? (unsigned)(n * p.Kpad + chunk * 4) * 4u : OOB;
     }
 
     const int kt_begin = blockIdx.z * p.ktiles_per_split;
     const int kt_end = min(kt_begin + p.ktiles_per_split, p.ktiles);
+    const bool tap_uniform = p.R * p.S > 1 && (p.Cin & (BK - 1)) == 0;    // a whole K step lies inside one filter tap
 
-    f32x4 ra[RA], rb[RB];
-    auto load_tile = [&](int kt) {
-        const int k = kt * BK + col4 * 4;
-        int c, dy = 0, dx = 0;
+    struct Regs { u32x4 a[RA], b[RB]; };
+    auto load_tile = [&](int kt, Regs &rg) {
+        int dy = 0, dx = 0, koff;         // koff: byte offset of this lane's 4 channels relative to rowoff (without the tap)
         bool kvalid;
-        if (p.R * p.S == 1) { c = k; kvalid = k < p.K; }
-        else {
-            const int rs = k >> p.log2Cin;
-            c = k & (p.Cin - 1);
-            kvalid = rs < p.R * p.S;
-            const int r = rs / p.S, s = rs - r * p.S;
+        if (p.R * p.S == 1) {
+            const int k = kt * BK + chunk * 4;
+            koff = kt * BK * 4; kvalid = k < p.K;
+        } else if (tap_uniform) {          // scalar tap decode
+            const int rs = (kt * BK) >> p.log2Cin;
+            const int r = (rs * p.inv_S) >> 16, s = rs - r * p.S;
             dy = r * p.dil; dx = s * p.dil;
+            koff = ((kt * BK) & (p.Cin - 1)) * 4; kvalid = rs < p.R * p.S;
+        } else {                           // narrow Cin (the 3-channel stems): taps differ between lanes
+            const int k = kt * BK + chunk * 4;
+            const int rs = k >> p.log2Cin;
+            const int r = (rs * p.inv_S) >> 16, s = rs - r * p.S;
+            dy = r * p.dil; dx = s * p.dil;
+            koff = (k & (p.Cin - 1)) * 4 - chunk * 16; kvalid = rs < p.R * p.S;
         }
+        const int tapoff = (dy * p.W + dx) * p.in_ld * 4 + koff;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int iy = iy0[i] + dy, ix = ix0[i] + dx;
             const bool ok = kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4 *>(gin + (size_t)(pbase[i] + iy * p.W + ix) * p.in_ld + c);
-            ra[i] = v;
+            rg.a[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, ok ? (unsigned)(rowoff[i] + tapoff) : OOB, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int n = n0 + row0 + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.Cout) v = *reinterpret_cast<const f32x4 *>(gw + (size_t)n * p.Kpad + k);
-            rb[i] = v;
-        }
+        for (int i = 0; i < RB; ++i) rg.b[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, woff[i] + (unsigned)(kt * BK * 4), 0, 0);
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const Regs &rg) {
         float *a = As + buf * BM * LDS_LD, *b = Bs + buf * BN * LDS_LD;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            if (MATH == ARSEG_MATH_F16X3) {
+            float *row = a + (row0 + RPP * i) * LDS_LD;
+            if (MATH == ARSEG_MATH_F16X3) {             // per 32-k tile: halves [0,32) hi, [32,64) lo
                 uint2 hi, lo;
-                split_f16x3(ra[i], hi, lo);
-                float *row = a + (row0 + 32 * i) * LDS_LD;
-                *reinterpret_cast<uint2 *>(row + col4 * 2) = hi;           // halves [0,32): hi
-                *reinterpret_cast<uint2 *>(row + 16 + col4 * 2) = lo;      // halves [32,64): lo
+                split_f16x3(__builtin_bit_cast(f32x4, rg.a[i]), hi, lo);
+                *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + (chunk & 7) * 2) = hi;
+                *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + 16 + (chunk & 7) * 2) = lo;
             } else {
-                *reinterpret_cast<f32x4 *>(a + (row0 + 32 * i) * LDS_LD + col4 * 4) = ra[i];
+                *reinterpret_cast<u32x4 *>(row + chunk * 4) = rg.a[i];
             }
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(b + (row0 + 32 * i) * LDS_LD + col4 * 4) = rb[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4 *>(b + (row0 + RPP * i) * LDS_LD + chunk * 4) = rg.b[i];
     };
 
     const int wave = tid >> 6, lane = tid & 63;
@@ -189,34 +206,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[0][r] = 0.0f;
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile(0);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);
-        const float *a = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
-        const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+    auto compute = [&](int cur) {
         if (MATH == ARSEG_MATH_F16X3) {
             // lane (li, lh) holds k = 16*ks + 8*lh + 0..7 of row li: one ds_read_b128 per operand and precision half
             const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
             const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
+                const int ko = (ks >> 1) * 32 + (ks & 1) * 8;      // float offset of this 16-k slice inside the row
                 h16x8 fah[TM], fal[TM], fbh[TN], fbl[TN];
 #pragma unroll
                 for (int t = 0; t < TM; ++t) {
-                    fah[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + ks * 8);
-                    fal[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + 16 + ks * 8);
+                    fah[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + ko);
+                    fal[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + 16 + ko);
                 }
 #pragma unroll
                 for (int t = 0; t < TN; ++t) {
-                    fbh[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + ks * 8);
-                    fbl[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + 16 + ks * 8);
+                    fbh[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + ko);
+                    fbl[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + 16 + ko);
                 }
                 if (DUAL) {
                     acc2[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[0], fbh[0], acc2[0], 0, 0, 0);
@@ -240,7 +247,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                             acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[tm], fbh[tn], acc[tm][tn], 0, 0, 0);
                 }
             }
-        } else
+        } else {
+            const float *a = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
+            const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
             f32x4 fa[TM], fb[TN];
@@ -256,13 +265,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     for (int tn = 0; tn < TN; ++tn)
                         acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[tm][kk], fb[tn][kk], acc[tm][tn], 0, 0, 0);
         }
-        if (NBUF == 2) {
-            if (more) store_tile(cur ^ 1);
+        }
+    };
+
+    Regs r0, r1;
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin, r0);
+        store_tile(0, r0);
+    }
+    if (NBUF == 2) {
+        // LDS double buffer + two register stages: the loads of K step kt+2 are issued before the MFMAs of step kt and are
+        // written to LDS a whole step later, so they have two compute phases to land; one barrier per step.
+        if (kt_begin + 1 < kt_end) load_tile(kt_begin + 1, r0);
+        __syncthreads();
+        int cur = 0;
+        auto step = [&](int kt, Regs &ld, Regs &st) {
+            if (kt + 2 < kt_end) load_tile(kt + 2, ld);
+            compute(cur);
+            if (kt + 1 < kt_end) store_tile(cur ^ 1, st);
             __syncthreads();
             cur ^= 1;
-        } else {                      // single LDS buffer: half the LDS per block (more blocks per CU), two barriers per step
+        };
+        for (int kt = kt_begin; kt < kt_end; kt += 2) {
+            step(kt, r1, r0);
+            if (kt + 1 < kt_end) step(kt + 1, r0, r1);
+        }
+    } else {
+        // single LDS buffer: half the LDS per block (more blocks per CU), two barriers per step
+        __syncthreads();
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const bool more = kt + 1 < kt_end;
+            if (more) load_tile(kt + 1, r0);
+            compute(0);
             __syncthreads();
-            if (more) store_tile(0);
+            if (more) store_tile(0, r0);
             __syncthreads();
         }
     }
@@ -314,7 +350,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     }
 }
 
-struct Plan { int bm, bn, nbuf, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
+struct Plan { int bm, bn, bk, nbuf, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
 
 int make_plan(const arseg_conv_desc *d, Plan *pl) {
     if (!d) return ARSEG_EINVAL;
@@ -332,9 +368,15 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->M = (int)M;
     pl->K = d->R * d->S * d->Cin;
     pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
-    pl->ktiles = pl->Kpad / BK;
+    if (d->tile_cfg < 0 || d->tile_cfg > 12) return ARSEG_EINVAL;
+    pl->bk = d->tile_cfg >= 9 ? 64 : 32;
+    pl->ktiles = (pl->Kpad + pl->bk - 1) / pl->bk;
+    // operands are addressed through 32-bit buffer offsets
+    if (((long long)d->N * d->H * d->W * d->in_ld + d->Cin) * 4 >= (1ll << 31) || (long long)d->Cout * pl->Kpad * 4 >= (1ll << 31))
+        return ARSEG_EUNSUPPORTED;
 
-    static const int cfg[9][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 128}};
+    static const int cfg[13][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 128},
+                                   {128, 128}, {128, 64}, {64, 64}, {64, 128}};
     // Tile / split-K choice, fitted to a brute-force sweep of this model family's layer shapes on MI355X
     // (scratch sweep recorded in DESIGN.md): aim for ~512 workgroups (2 per CU); take the largest tile that gets
     // there with a split-K factor that still leaves >= 8 K-steps per slice; shallow GEMMs (< 64 K-steps) are best
@@ -343,7 +385,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     const int max_split = pl->ktiles / 8 > 0 ? (pl->ktiles / 8 > 16 ? 16 : pl->ktiles / 8) : 1;
     int bm = 64, bn = 64, nsplit = 1;
     pl->nbuf = (d->tile_cfg >= 1 && d->tile_cfg <= 4) ? 2 : 1;     // single LDS buffer (more blocks per CU) measured faster
-    if (d->tile_cfg >= 1 && d->tile_cfg <= 8) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
+    if (d->tile_cfg >= 1) { bm = cfg[d->tile_cfg][0]; bn = cfg[d->tile_cfg][1]; }
     else {
         const int order_deep[4] = {1, 4, 2, 3}, order_shallow[4] = {3, 3, 3, 3};
         const int *order = pl->ktiles >= 64 ? order_deep : order_shallow;
@@ -365,7 +407,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->tiles_m = arseg_cdiv(M, bm);
     pl->tiles_n = arseg_cdiv(d->Cout, bn);
     if (d->split_k > 0) nsplit = d->split_k;
-    else if (d->tile_cfg >= 1 && d->tile_cfg <= 8) {
+    else if (d->tile_cfg >= 1) {
         const long long tiles = (long long)pl->tiles_m * pl->tiles_n;
         const long long need = (target + tiles - 1) / tiles;
         nsplit = (int)(need < 1 ? 1 : (need > max_split ? max_split : need));
@@ -378,40 +420,40 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     return ARSEG_OK;
 }
 
-template <int BM, int BN, int NBUF, int MATH>
+template <int BM, int BN, int BK, int NBUF, int MATH>
 int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
-    const size_t smem = (size_t)NBUF * (BM + BN) * LDS_LD * sizeof(float);
+    const size_t smem = (size_t)NBUF * (BM + BN) * (BK + 4) * sizeof(float);
     static bool attr_set = false;     // idempotent; a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, NBUF, MATH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, BK, NBUF, MATH>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, p.in_bs || p.w_bs || p.out_bs ? p.N_batch : 1, pl.nsplit);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, NBUF, MATH>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, NBUF, MATH>), grid, dim3(256), smem, st, p);
     return arseg_launch_status();
+}
+
+template <int BK, int NBUF, int MATH>
+int launch_tile(const ConvParams &p, const Plan &pl, hipStream_t hs) {
+    if (pl.bm == 128 && pl.bn == 128) return launch<128, 128, BK, NBUF, MATH>(p, pl, hs);
+    if (pl.bm == 128 && pl.bn == 64) return launch<128, 64, BK, NBUF, MATH>(p, pl, hs);
+    if (pl.bm == 64 && pl.bn == 128) return launch<64, 128, BK, NBUF, MATH>(p, pl, hs);
+    return launch<64, 64, BK, NBUF, MATH>(p, pl, hs);
 }
 
 template <int MATH>
 int launch_math(const ConvParams &p, const Plan &pl, hipStream_t hs) {
-    if (pl.nbuf == 1) {
-        if (pl.bm == 128 && pl.bn == 128) return launch<128, 128, 1, MATH>(p, pl, hs);
-        if (pl.bm == 128 && pl.bn == 64) return launch<128, 64, 1, MATH>(p, pl, hs);
-        if (pl.bm == 64 && pl.bn == 128) return launch<64, 128, 1, MATH>(p, pl, hs);
-        return launch<64, 64, 1, MATH>(p, pl, hs);
-    }
-    if (pl.bm == 128 && pl.bn == 128) return launch<128, 128, 2, MATH>(p, pl, hs);
-    if (pl.bm == 128 && pl.bn == 64) return launch<128, 64, 2, MATH>(p, pl, hs);
-    if (pl.bm == 64 && pl.bn == 128) return launch<64, 128, 2, MATH>(p, pl, hs);
-    return launch<64, 64, 2, MATH>(p, pl, hs);
+    if (pl.bk == 64) return launch_tile<64, 1, MATH>(p, pl, hs);
+    return pl.nbuf == 1 ? launch_tile<32, 1, MATH>(p, pl, hs) : launch_tile<32, 2, MATH>(p, pl, hs);
 }
 
 }  // namespace
 
 extern "C" int arseg_packed_k(int Cin_pad, int R, int S) {
     const int K = R * S * Cin_pad;
-    return (K + BK - 1) / BK * BK;
+    return (K + KALIGN - 1) / KALIGN * KALIGN;
 }
 
 extern "C" int arseg_conv_out_hw(const arseg_conv_desc *d, int *Ho, int *Wo) {
@@ -448,6 +490,9 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld;
     p.log2Cin = 0;
     while ((1 << p.log2Cin) < d->Cin) ++p.log2Cin;
+    p.inv_S = 65536 / d->S + 1;
+    p.in_bytes = (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);
+    p.w_bytes = (unsigned)((long long)d->Cout * pl.Kpad * 4);
     p.Ho = pl.Ho; p.Wo = pl.Wo; p.Cout = d->Cout; p.out_ld = d->out_ld; p.res_ld = d->res_ld;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.K = pl.K; p.Kpad = pl.Kpad; p.M = pl.M;
@@ -517,7 +562,7 @@ static inline float f16_to_f32(uint16_t h) {
 }
 
 extern "C" int arseg_split_weight_f16x3_host(const float *w_packed, int Cout, int Kpad, void *out_host, float *chan_mul_inv) {
-    if (!w_packed || !out_host || Cout <= 0 || Kpad <= 0 || (Kpad % BK)) return ARSEG_EINVAL;
+    if (!w_packed || !out_host || Cout <= 0 || Kpad <= 0 || (Kpad % KALIGN)) return ARSEG_EINVAL;
     uint16_t *o = reinterpret_cast<uint16_t *>(out_host);
     for (int co = 0; co < Cout; ++co) {
         const float *row = w_packed + (size_t)co * Kpad;
@@ -532,6 +577,7 @@ extern "C" int arseg_split_weight_f16x3_host(const float *w_packed, int Cout, in
             if (e < -100) e = -100;
         }
         if (chan_mul_inv) chan_mul_inv[co] = ldexpf(1.0f, -e);
+        constexpr int BK = KALIGN;
         for (int kt = 0; kt < Kpad / BK; ++kt)
             for (int j = 0; j < BK; ++j) {
                 const float x = ldexpf(row[kt * BK + j], e);

@@ -331,9 +331,9 @@ _conv_plans = _PlanCache()
 
 def _conv_candidates(ktiles: int, cout: int, m: int):
     cands = []
-    for cfg in (5, 6, 7, 8, 1):
-        bn = 128 if cfg in (5, 8, 1) else 64
-        bm = 128 if cfg in (5, 6, 1) else 64
+    for cfg in (5, 6, 7, 8, 9, 10, 11, 12):
+        bn = 128 if cfg in (5, 8, 9, 12) else 64
+        bm = 128 if cfg in (5, 6, 9, 10) else 64
         if bn == 128 and cout <= 64:
             continue
         if bm == 128 and m <= 64:
@@ -467,8 +467,8 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
 
     if plan is None:
         best, best_t = 0, float("inf")
-        for cfg in (0, 5, 6, 7, 8, 1):
-            if cfg in (5, 8, 1) and Cout <= 64:
+        for cfg in (0, 5, 6, 7, 8, 9, 10, 11, 12):
+            if cfg in (5, 8, 9, 12) and Cout <= 64:
                 continue
             t = _time(lambda: gemm(cfg, False))
             if t < best_t:

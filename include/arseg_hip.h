@@ -118,8 +118,8 @@ typedef struct arseg_conv_desc {
     int R, S, stride, pad, dil;
     int act;           /* enum arseg_act */
     float prelu_slope; /* single shared slope (nn.PReLU() default, model/pspnet.py:40) */
-    int tile_cfg;      /* 0 auto; 1..4 = 128x128, 128x64, 64x64, 64x128 with a double-buffered LDS tile; 5..8 = the same
-                          tiles single-buffered (half the LDS, more workgroups per CU) */
+    int tile_cfg;      /* 0 auto; 1..4 = 128x128, 128x64, 64x64, 64x128 (K step 32) with a double-buffered LDS tile; 5..8 = the
+                          same tiles single-buffered (half the LDS, more workgroups per CU); 9..12 = single-buffered, K step 64 */
     int split_k;       /* 0 auto, >= 1 explicit */
     /* batched mode (used by the Winograd path): `batch` independent problems of identical shape, problem b reads
        in + b*in_batch_stride, w_packed + b*w_batch_stride and writes out + b*out_batch_stride (strides in floats);

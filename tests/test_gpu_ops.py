@@ -265,7 +265,8 @@ def test_conv2d(dev, case, conv_math):
     xd = xn.to(dev)
     rd = None if res is None else res.permute(0, 2, 3, 1).contiguous().to(dev)
     tol = 2e-4
-    for tile_cfg, split_k in ((0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (3, 3), (7, 3), (1, 2), (5, 2)):
+    for tile_cfg, split_k in ((0, 0), (1, 1), (2, 1), (3, 1), (4, 1), (5, 1), (6, 1), (7, 1), (8, 1), (9, 1), (10, 1), (11, 1), (12, 1),
+                              (3, 3), (7, 3), (1, 2), (5, 2), (11, 2), (9, 3)):
         if split_k > 1 and Cout % 4:
             continue
         got = ops.conv2d(xd, pc, residual=rd, tile_cfg=tile_cfg, split_k=split_k).permute(0, 3, 1, 2).cpu()
