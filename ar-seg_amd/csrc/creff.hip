@@ -30,17 +30,11 @@
 // so a wave's ds_read_b128 covers 32 consecutive 16-byte slots = conflict free.
 // fp32 throughout (VALU); the banded QK^T wastes >75% of an fp32 MFMA tile, which runs at the VALU
 // rate anyway (MI355X_MICROARCH: v_mfma_f32_* = 64 FLOP/clk/SIMD), so MFMA would be slower here.
-#include "arseg_common.h"
+#include "creff_params.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
-
-struct CreffParams {
-    const float *hr, *lr, *wq, *bq, *wk, *bk, *wv, *bv, *wf, *bf;
-    float *p_out, *logits;
-    int N, C, Hp, Wp, hp, wp, n_cls, log_softmax;
-    unsigned p_bytes, l_bytes;
-    float sy, sx;   // align_corners=True source scales (hp-1)/(Hp-1), (wp-1)/(Wp-1)
-};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -524,6 +518,16 @@ extern "C" int arseg_creff_fwd(const float *hr, const float *lr, const float *wq
     p.sy = arseg_resize_scale(hp, Hp, true); p.sx = arseg_resize_scale(wp, Wp, true);
     hipStream_t st = arseg_stream(stream);
     if (kH == 7) {
+        // Two implementations.  The matrix-core kernel (creff_mfma.hip: 16-wave workgroups, 16x16 tiles) wins on wide features
+        // and small maps (BiSeNet, C=256 at 1/8 resolution: 151 us vs 652 us per frame on MI355X); on the 64-channel
+        // full-resolution PSPNet feature the fp32 VALU kernel below is still ahead (363 us vs 388 us).  ARSEG_CREFF_IMPL=mfma|valu
+        // pins one of them (A/B measurements, tests).
+        const char *e = getenv("ARSEG_CREFF_IMPL");      // read per call: tests switch it
+        const int impl = !e ? 0 : (strcmp(e, "mfma") == 0 ? 1 : (strcmp(e, "valu") == 0 ? 2 : 0));
+        if (impl == 1 || (impl == 0 && C >= 128)) {
+            const int st_m = arseg_creff_mfma_launch(p, st);
+            if (st_m != ARSEG_EUNSUPPORTED) return st_m;
+        }
         if (!head) return dispatch_th<7, 0>(p, st);
         if (n_cls <= 12) return dispatch_th<7, 12>(p, st);
         if (n_cls <= 19) return dispatch_th<7, 19>(p, st);

@@ -1,0 +1,440 @@
+// CReFF with the two contractions of the local attention (Q.K^T over channels, P.V over the window) on the gfx950 matrix
+// cores.  Same arithmetic contract as creff.hip (reference: MyAttention.forward, model/attention.py:184-213, followed by
+// the frozen 1x1 classifier, model/pspnet.py:225-229 / model/bisenet.py:571-572); that file holds the fp32 VALU version,
+// which remains the fallback for window sizes other than 7x7 and for shapes this kernel does not cover.
+//
+// fp32 on fp16 MFMAs.  Every fp32 operand x is split into hi + lo (two fp16, 22 significant bits together).  The K index
+// of v_mfma_f32_16x16x32_f16 is packed as [4 hi | 4 lo] per lane, so MFMA(A={a_hi,a_lo}, B={b_hi,b_lo}) yields
+// a_hi.b_hi + a_lo.b_lo and MFMA(A, B'={b_lo,b_hi}) the two cross terms: two instructions give the full fp32-grade product.
+//
+// Geometry.  A workgroup (16 waves) owns a 16x16 pixel tile; a wave owns an 8x2 patch of queries.  The 7x7 windows of a
+// patch lie inside 8 rows x 14 columns of keys; padded to 8 x 16 = 128 key slots this is 8 MFMA row blocks, block b =
+// window row b, slot kx = window column (49 of the 128 scores per query are real, the rest are masked before the softmax).
+//   scores   D[key kx][query] (block b) += K[row b][kx][16 ch] . Q[query][16 ch]      A = K from LDS, B = Q in registers
+//   softmax  in registers: a query's 128 slots live in 4 lanes x 32 registers (two xor-shuffles for max and sum)
+//   values   D[ch][query] += V[row b][kx][ch] . P[kx][query]    A = V through ds_read_b64_tr_b16 (LDS transpose read),
+//            B = P: the score registers are already in B-operand order, nothing moves between lanes
+//   head     D[class][query] += Wf[class][16 ch] . p[query][16 ch]   B = the fused feature, again in D order
+// Channels are processed in chunks of 16: the warped keyframe chunk (+halo) is staged in LDS, the depthwise 3x3 key /
+// value convolution runs on the VALU and writes its result as split fp16 records ([group of 4 ch][px]{4 hi | 4 lo}, zero outside the
+// image = the unfold's padding, model/attention.py:56-58), the query convolution is lane-local (each lane convolves the
+// 4 channels of its own query that its B operand needs).
+#include "creff_params.h"
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
+
+constexpr int TX = 16, TY = 16, NT = 1024;
+constexpr int G = 4;                                  // float4 groups per 16-channel chunk
+constexpr int RH = 22, RW = 24, RWC = 22;             // key/value region: rows, record columns, computed columns
+constexpr int KPLK = RH * RW, KPLV = RH * RW + 4;     // plane stride of the key / value records: keys are read with ds_read_b128
+                                                      // (planes on the same banks), values with the transpose read (planes 16 banks apart)
+constexpr int HH = 24, HWD = 26, HPL = HH * HWD;      // staged hr chunk (+3 window halo +1 conv halo), one plane per group
+constexpr int LH = 18, LWD = 18, LPL = LH * LWD + 4;  // upsampled lr tile (+1 conv halo)
+constexpr int LWCAP = 512;                            // raw lr window capacity (float4): 128 low-resolution pixels
+constexpr unsigned OOB = 0xFFFFFFF0u;
+constexpr float LOG2E = 1.44269504088896340736f;
+
+__device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
+    float h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFFE000u);   // 11 significant bits: exact in fp16
+        l[j] = v[j] - h[j];
+    }
+    hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
+    hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
+    lo.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[0], l[1]));
+    lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
+}
+// {hi, lo, hi}: dwords 0..3 are the operand {hi,lo}, dwords 2..5 the swapped operand {lo,hi} -- no register copies
+__device__ __forceinline__ u32x6 pack6(const u32x2 hi, const u32x2 lo) { return u32x6{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y}; }
+__device__ __forceinline__ h16x8 op_a(const u32x6 v) { return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
+__device__ __forceinline__ h16x8 op_b(const u32x6 v) { return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 2, 3, 4, 5)); }
+__device__ __forceinline__ h16x8 pack8(const u32x2 a, const u32x2 b) { return __builtin_bit_cast(h16x8, u32x4{a.x, a.y, b.x, b.y}); }
+__device__ __forceinline__ u32x2 lds_tr16(const unsigned char *p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)p));
+}
+
+// Asynchronous memory traffic is issued through inline asm on purpose.  hipcc (ROCm 7.2) serialises the LDS-DMA builtins
+// (a waterfall loop over the M0 base with an s_waitcnt vmcnt(0) in front of every load) and, on gfx9, drains every counter it
+// knows about in front of each s_barrier -- so builtin stores would expose the full write latency at the next barrier.
+// Loads: waited for explicitly (s_waitcnt vmcnt(0)) before the barrier that publishes their LDS image.  Stores: fire and
+// forget (their data registers are read at issue).
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;      // wave uniform: pin the descriptor to SGPRs
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void dma16_buf(const u32x4 rsrc, unsigned voff, unsigned lds_base) {   // LDS[lds_base + lane*16] <- buffer
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void dma16_glb(const void *g, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(g) : "memory");
+}
+__device__ __forceinline__ void store16_buf(const u32x4 v, const u32x4 rsrc, unsigned voff) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigned voff) {
+    asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
+
+template <int NB>      // classifier row blocks of 16 classes (0: no head)
+__global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
+    constexpr int NBA = NB > 0 ? NB : 1;
+    extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
+    f32x4 *Hs = smem4;                          // [2][G][HPL]   (double buffered, filled by LDS-DMA)
+    f32x4 *Ls = Hs + 2 * G * HPL;               // [G][LPL]
+    f32x4 *Lw = Ls + G * LPL;                   // [2] raw lr window [G][px]
+    f32x4 *Wd = Lw + 2 * LWCAP;                 // [2][3 convs][9 taps + bias][G]
+    f32x4 *Wfs = Wd + 2 * 3 * 10 * G;           // [2][G][NBA*16]: classifier slice of a chunk, {4 hi | 4 lo} halves per entry
+    f32x4 *Tb = Wfs + 2 * G * NBA * 16;         // bilinear tables: [LH] rows then [LWD] columns of the lr_up tile
+    u32x4 *Kl = reinterpret_cast<u32x4 *>(Tb + LH + LWD);   // key / value records [G][RH*RW]: {4 hi halves | 4 lo halves}
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 15, g = lane >> 4, qy = q >> 3, qx = q & 7;
+    const int pc = wave & 1, pr = wave >> 1;
+    // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (private L2s); give each XCD a
+    // contiguous run of tiles so that the halos neighbouring tiles share are fetched into one L2 only
+    int n, ty0, tx0;
+    {
+        const int tiles_x = gridDim.x, per_img = gridDim.x * gridDim.y, nblk = per_img * gridDim.z;
+        int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int qn = nblk >> 3, rn = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
+        n = bid / per_img;
+        const int rem = bid - n * per_img;
+        ty0 = (rem / tiles_x) * TY; tx0 = (rem - (rem / tiles_x) * tiles_x) * TX;
+    }
+    const int CB = p.C >> 4;
+    const int yq = 2 * pr + qy, xq = 8 * pc + qx;               // this lane's query pixel, tile relative
+    const int gyq = ty0 + yq, gxq = tx0 + xq;
+
+    // window of the low-resolution feature under the tile (+1 halo), block uniform (see creff.hip)
+    int ly_lo, ly_n, lx_lo, lx_n;
+    {
+        int a0, a1, b0, b1; float l;
+        arseg_src_index(p.sy, max(ty0 - 1, 0), true, p.hp, a0, a1, l);
+        arseg_src_index(p.sy, min(ty0 + TY, p.Hp - 1), true, p.hp, b0, b1, l);
+        ly_lo = a0; ly_n = b1 - a0 + 1;
+        arseg_src_index(p.sx, max(tx0 - 1, 0), true, p.wp, a0, a1, l);
+        arseg_src_index(p.sx, min(tx0 + TX, p.Wp - 1), true, p.wp, b0, b1, l);
+        lx_lo = a0; lx_n = b1 - a0 + 1;
+    }
+    // bilinear(align_corners=True) taps of the tile rows / columns (tile coordinate -1 .. 16), once per tile:
+    // {offset of tap 0 in the window, offset of tap 1, weight of tap 1, inside the image}
+    if (tid < LH + LWD) {
+        const bool row = tid < LH;
+        const int rel = row ? tid : tid - LH;
+        const int gc = (row ? ty0 : tx0) - 1 + rel, lim = row ? p.Hp : p.Wp;
+        int i0, i1; float l1;
+        arseg_src_index(row ? p.sy : p.sx, min(max(gc, 0), lim - 1), true, row ? p.hp : p.wp, i0, i1, l1);
+        l1 = fminf(fmaxf(l1, 0.f), 1.f);
+        const int o0 = row ? (i0 - ly_lo) * lx_n : i0 - lx_lo, o1 = row ? (i1 - ly_lo) * lx_n : i1 - lx_lo;
+        Tb[tid] = f32x4{__int_as_float(o0), __int_as_float(o1), l1, (unsigned)gc < (unsigned)lim ? 1.0f : 0.0f};
+    }
+    // bilinear sample of the staged lr window at tile row r / column c (table indices), channel group gg
+    auto lr_up = [&](const f32x4 *win, int r, int c, int gg) {
+        const f32x4 ty = Tb[r], tx = Tb[LH + c];
+        const f32x4 *b = win + gg * (ly_n * lx_n);      // one plane per channel group
+        const int r0 = __float_as_int(ty[0]), r1 = __float_as_int(ty[1]), x0 = __float_as_int(tx[0]), x1 = __float_as_int(tx[1]);
+        const f32x4 a = b[r0 + x0], bb = b[r0 + x1], cc = b[r1 + x0], d = b[r1 + x1];
+        const float ly = ty[2], lx2 = tx[2];
+        return (1.f - ly) * ((1.f - lx2) * a + lx2 * bb) + ly * ((1.f - lx2) * cc + lx2 * d);
+    };
+
+    // Per-thread work items of the staging / convolution rounds do not depend on the channel chunk: decode them once.
+    constexpr int H_TOT = G * HH * HWD, H_NI = (H_TOT + NT - 1) / NT;
+    constexpr int K_TOT = G * RH * RWC, K_NI = (K_TOT + NT - 1) / NT;
+    constexpr int L_TOT = G * LH * LWD, L_NI = (L_TOT + NT - 1) / NT;
+    constexpr unsigned BAD = 0x80000000u;             // beyond num_records even after the chunk offset is added
+    unsigned hoff[H_NI];                               // byte offset inside the image's first chunk, or BAD
+#pragma unroll
+    for (int it = 0; it < H_NI; ++it) {
+        const int i = tid + it * NT;                   // = index in the Hs image (the LDS-DMA destination is lane linear)
+        const int gg = i / HPL, px = i - gg * HPL, r = px / HWD, c = px - r * HWD;
+        const int gy = ty0 - 4 + r, gx = tx0 - 4 + c;
+        const bool ok = i < H_TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
+        hoff[it] = ok ? (unsigned)((((gg >> 1) * p.Hp + gy) * p.Wp + gx) * 8 + (gg & 1) * 4) * 4u : BAD;
+    }
+    int kh[K_NI], kk[K_NI], kg[K_NI];                  // Hs read index, Kl write index, channel group
+    bool kin[K_NI];
+#pragma unroll
+    for (int it = 0; it < K_NI; ++it) {
+        const int i = min(tid + it * NT, K_TOT - 1);   // surplus lanes of the last round redo the last item
+        const int gg = i / (RH * RWC), rem = i - gg * (RH * RWC), r = rem / RWC, c = rem - r * RWC;
+        kh[it] = gg * HPL + r * HWD + c; kk[it] = r * RW + c; kg[it] = gg;
+        kin[it] = (unsigned)(ty0 - 3 + r) < (unsigned)p.Hp && (unsigned)(tx0 - 3 + c) < (unsigned)p.Wp;
+    }
+    int lrc_[L_NI];                                    // lr_up tile items: row | col << 8 | group << 16, -1 = none
+#pragma unroll
+    for (int it = 0; it < L_NI; ++it) {
+        const int i = tid + it * NT;                   // group slowest: consecutive lanes write consecutive LDS slots
+        const int gg = i / (LH * LWD), px = i - gg * (LH * LWD), r = px / LWD, c = px - r * LWD;
+        lrc_[it] = i < L_TOT ? (r | (c << 8) | (gg << 16)) : -1;
+    }
+    const u32x4 h_rsrc = make_rsrc(p.hr + (size_t)n * p.C * p.Hp * p.Wp, (unsigned)((size_t)p.C * p.Hp * p.Wp * sizeof(float)));
+    const unsigned h_chunk = (unsigned)(2 * p.Hp * p.Wp * 8) * 4u;      // bytes between 16-channel chunks (C8 layout)
+
+    // Staging is asynchronous: the next chunk's hr region, lr window and depthwise weights go global -> LDS directly
+    // (LDS-DMA, no staging registers) into the other half of double buffers while the current chunk is convolved and
+    // multiplied.  With one 16-wave workgroup per CU nothing else would hide the memory latency.  Out-of-image hr elements
+    // carry an out-of-range buffer offset and arrive as zeros (the conv's zero padding).
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int lw_tot = G * ly_n * lx_n;
+    f32x4 pf_w;
+    auto issue = [&](int k, int buf, bool head) {
+#pragma unroll
+        for (int it = 0; it < H_NI; ++it)
+            if (it * NT + wave_u * 64 < H_TOT)
+                dma16_buf(h_rsrc, hoff[it] + k * h_chunk, lds_addr(Hs + buf * G * HPL + it * NT + wave_u * 64));
+        if (wave_u * 64 < lw_tot) {
+            const int i = min(tid, lw_tot - 1);          // surplus lanes of the last wave repeat the last item (stay inside Lw)
+            const int npx = ly_n * lx_n, gg = i / npx, px = i - gg * npx, r = px / lx_n, c = px - r * lx_n;
+            const float *src = p.lr + ((size_t)n * p.hp * p.wp + (size_t)(ly_lo + r) * p.wp + lx_lo + c) * p.C + k * 16 + gg * 4;
+            if (tid < lw_tot) dma16_glb(src, lds_addr(Lw + buf * LWCAP + wave_u * 64));
+        }
+        if (wave_u * 64 < 3 * 10 * G) {                  // depthwise weights [9][C] + biases of the chunk
+            const int t = min(tid, 3 * 10 * G - 1);
+            const int gg = t & 3, tp = (t >> 2) % 10, cv = t / (G * 10);
+            const float *w = cv == 0 ? p.wq : (cv == 1 ? p.wk : p.wv);
+            const float *bb = cv == 0 ? p.bq : (cv == 1 ? p.bk : p.bv);
+            const int c = k * 16 + gg * 4;
+            const float *src = tp < 9 ? w + (size_t)tp * p.C + c : bb + c;
+            if (tid < 3 * 10 * G) dma16_glb(src, lds_addr(Wd + buf * 3 * 10 * G + wave_u * 64));
+        }
+        if (NB > 0 && head && tid < G * NBA * 16) {   // classifier slice [class][16 ch] of the chunk, entry = (group, class)
+            const int cls = tid % (NBA * 16), gg = tid / (NBA * 16);
+            pf_w = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cls < p.n_cls) pf_w = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)cls * p.C + k * 16 + gg * 4);
+        }
+    };
+    auto commit_head = [&](int buf) {
+        if (NB > 0 && tid < G * NBA * 16) {
+            u32x2 hi, lo;
+            split4(pf_w, hi, lo);
+            Wfs[buf * G * NBA * 16 + tid] = __builtin_bit_cast(f32x4, u32x4{hi.x, hi.y, lo.x, lo.y});
+        }
+    };
+    // key (cv=1) or value (cv=2) records of the region: bias + dw3x3(Hs), zero outside the image, split to fp16 hi/lo
+    auto conv_kv = [&](int cv, int buf) {
+        const f32x4 *w = Wd + (buf * 3 + cv) * 10 * G, *hs = Hs + buf * G * HPL;
+#pragma unroll
+        for (int it = 0; it < K_NI; ++it) {
+            const f32x4 *h = hs + kh[it];
+            const f32x4 *wg = w + kg[it];
+            f32x4 acc = wg[9 * G];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) acc += wg[(dy * 3 + dx) * G] * h[dy * HWD + dx];
+            if (!kin[it]) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            u32x2 hi, lo;
+            split4(acc, hi, lo);
+            Kl[kk[it] + kg[it] * (cv == 1 ? KPLK : KPLV)] = u32x4{hi.x, hi.y, lo.x, lo.y};
+        }
+    };
+
+    // the two record columns that only pad the windows to 16 slots are never computed: zero them once
+    if (tid < G * RH * 2) {
+        const int gg = tid / (RH * 2), e = ((tid % (RH * 2)) >> 1) * RW + RWC + (tid & 1);
+        Kl[gg * KPLK + e] = u32x4{0, 0, 0, 0};
+        Kl[gg * KPLV + e] = u32x4{0, 0, 0, 0};       // (the two layouts overlap; both sets of pad columns stay zero)
+    }
+
+    const u32x4 *ka = Kl + g * KPLK + (2 * pr) * RW + 8 * pc + q;             // A operand of the scores, row block 0
+    // transpose read: lane i of a 16-lane group supplies the 8-byte piece (pixel 4g + i/4, channel group i%4) and receives
+    // channel i of the group's 4 pixels (verified on gfx950: out[i][j] = halfword i%4 of the piece of lane 4j + i/4)
+    const unsigned char *va = reinterpret_cast<const unsigned char *>(Kl + (q & 3) * KPLV + (2 * pr) * RW + 8 * pc + 4 * g + (q >> 2));
+
+    f32x4 S[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) S[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ------------------------------------------------------------------ pass 1: scores
+    issue(0, 0, false);
+    for (int k = 0; k < CB; ++k) {
+        const int buf = k & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's share of chunk k has landed
+        __syncthreads();                         // ... everybody's has; everybody is done with the other buffers
+        issue(k + 1 < CB ? k + 1 : 0, buf ^ 1, k + 1 == CB);      // after the last chunk: chunk 0 again, for pass 2
+#pragma unroll
+        for (int it = 0; it < L_NI; ++it) {
+            const int code = lrc_[it];
+            if (code >= 0) {
+                const int r = code & 255, c = (code >> 8) & 255, gg = code >> 16;
+                f32x4 v = lr_up(Lw + buf * LWCAP, r, c, gg);
+                if (Tb[r][3] * Tb[LH + c][3] == 0.f) v = f32x4{0.f, 0.f, 0.f, 0.f};      // conv zero padding outside the image
+                Ls[gg * LPL + r * LWD + c] = v;
+            }
+        }
+        conv_kv(1, buf);
+        __syncthreads();
+        // query conv, lane local: channels 4g..4g+3 of this lane's own pixel
+        const f32x4 *w = Wd + (buf * 3 + 0) * 10 * G;
+        f32x4 qv = w[9 * G + g];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) qv += w[(dy * 3 + dx) * G + g] * Ls[g * LPL + (yq + dy) * LWD + xq + dx];
+        u32x2 qh, ql;
+        split4(qv, qh, ql);
+        const u32x6 q6 = pack6(qh, ql);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const h16x8 a = __builtin_bit_cast(h16x8, ka[b * RW]);
+            S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_a(q6), S[b], 0, 0, 0);
+            S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_b(q6), S[b], 0, 0, 0);
+        }
+        if (k + 1 == CB) commit_head(buf ^ 1);
+    }
+
+    // ------------------------------------------------------------------ softmax over the 49 taps (padding taps included)
+    // S[b][i] = score(query q, key row b, key column 4g+i); tap (b - qy, 4g+i - qx) is real iff both are in [0,6]
+    float inv;
+    u32x6 P6[8];
+    {
+        bool colok[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) colok[i] = (unsigned)(4 * g + i - qx) <= 6u;
+        float m = -INFINITY;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool rowok = (unsigned)(b - qy) <= 6u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                S[b][i] = (rowok && colok[i]) ? S[b][i] : -INFINITY;
+                m = fmaxf(m, S[b][i]);
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const float ml = m * LOG2E;
+        float z = 0.f;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                S[b][i] = __builtin_amdgcn_exp2f(fmaf(S[b][i], LOG2E, -ml));     // masked slots: exp2(-inf) = 0
+                z += S[b][i];
+            }
+            u32x2 hi, lo;
+            split4(S[b], hi, lo);
+            P6[b] = pack6(hi, lo);
+        }
+        z += __shfl_xor(z, 16);
+        z += __shfl_xor(z, 32);
+        inv = 1.0f / z;                            // applied to the weighted sum instead of the 128 weights
+    }
+
+    f32x4 lg[NBA];
+#pragma unroll
+    for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool inq = gyq < p.Hp && gxq < p.Wp;
+    const u32x4 p_rsrc = make_rsrc(p.p_out, p.p_bytes), l_rsrc = make_rsrc(p.logits, p.l_bytes);
+
+    // ------------------------------------------------------------------ pass 2: weighted values, residual, head
+    for (int k = 0; k < CB; ++k) {
+        const int buf = (k + CB) & 1;            // continues the alternation of pass 1
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < CB) issue(k + 1, buf ^ 1, true);
+        conv_kv(2, buf);
+        const f32x4 lrc = lr_up(Lw + buf * LWCAP, yq + 1, xq + 1, g);      // residual term, channels 4g..4g+3 (table rows clamp into the image)
+        __syncthreads();
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const h16x8 a = pack8(lds_tr16(va + b * RW * 16), lds_tr16(va + b * RW * 16 + 8));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_a(P6[b]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_b(P6[b]), acc, 0, 0, 0);
+        }
+        const f32x4 o = lrc + acc * inv;              // p[query][16k + 4g .. +3]
+        const unsigned off = (unsigned)(((((size_t)n * (p.C >> 3) + 2 * k + (g >> 1)) * p.Hp + gyq) * p.Wp + gxq) * 8 + (g & 1) * 4) * 4u;
+        store16_buf(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? off : OOB);
+        if (NB > 0) {
+            u32x2 oh, ol;
+            split4(o, oh, ol);
+            const u32x6 o6 = pack6(oh, ol);
+#pragma unroll
+            for (int nb = 0; nb < NBA; ++nb) {
+                const h16x8 wa = __builtin_bit_cast(h16x8, Wfs[(buf * G + g) * NBA * 16 + nb * 16 + q]);
+                lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, op_a(o6), lg[nb], 0, 0, 0);
+                lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, op_b(o6), lg[nb], 0, 0, 0);
+            }
+        }
+        if (k + 1 < CB) commit_head(buf ^ 1);
+    }
+
+    // ------------------------------------------------------------------ logits: lg[nb][i] = class 16nb + 4g + i of query q
+    if (NB > 0) {
+        float m = -INFINITY;
+#pragma unroll
+        for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cls = nb * 16 + 4 * g + i;
+                lg[nb][i] += p.bf[min(cls, p.n_cls - 1)];
+                m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
+            }
+        if (p.log_softmax) {
+            m = fmaxf(m, __shfl_xor(m, 16));
+            m = fmaxf(m, __shfl_xor(m, 32));
+            float z = 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? expf(lg[nb][i] - m) : 0.f;
+            z += __shfl_xor(z, 16);
+            z += __shfl_xor(z, 32);
+            const float lse = m + logf(z);
+#pragma unroll
+            for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
+        }
+#pragma unroll
+        for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cls = nb * 16 + 4 * g + i;
+                const unsigned off = (unsigned)(((((size_t)n * p.n_cls + cls) * p.Hp + gyq) * p.Wp + gxq) * sizeof(float));
+                store4_buf(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB);
+            }
+    }
+}
+
+template <int NB>
+int launch(const CreffParams &p, hipStream_t st) {
+    constexpr int NBA = NB > 0 ? NB : 1;
+    const size_t smem = ((size_t)2 * G * HPL + (size_t)G * LPL + 2 * LWCAP + 2 * 3 * 10 * G + 2 * G * NBA * 16) * sizeof(f32x4) + (LH + LWD) * sizeof(f32x4) + (size_t)G * KPLV * sizeof(u32x4);
+    static bool attr_set = false;     // idempotent; a race only repeats the same call
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_mfma_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(arseg_cdiv(p.Wp, TX), arseg_cdiv(p.Hp, TY), p.N);
+    hipLaunchKernelGGL((creff_mfma_kernel<NB>), grid, dim3(NT), smem, st, p);
+    return arseg_launch_status();
+}
+
+}  // namespace
+
+int arseg_creff_mfma_launch(const CreffParams &p, hipStream_t st) {
+    if (p.C & 15) return ARSEG_EUNSUPPORTED;
+    // the raw lr window under a tile (+1 halo, +1 for the second bilinear tap) must fit its LDS slot
+    const int wy = (int)((TY + 1) * p.sy) + 3, wx = (int)((TX + 1) * p.sx) + 3;
+    if (G * wy * wx > LWCAP) return ARSEG_EUNSUPPORTED;
+    if (p.n_cls > 32) return ARSEG_EUNSUPPORTED;
+    if (p.n_cls == 0) return launch<0>(p, st);
+    return p.n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
+}
