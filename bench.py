@@ -13,7 +13,12 @@ A "step" is one GOP per rank, i.e. one pass of the hot path over one batch of sy
 All inputs (frames, int16 MV maps, weights) are resident in HBM before the timed region.  `value` counts the
 non-keyframes only, while the keyframe's HR forward and the exchange are inside the timed region (nothing skipped).
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the fp32-MFMA implicit-GEMM conv), `roofline_creff`
+Arithmetic: fp32 tensors end to end.  The convolution GEMMs are evaluated on the fp16 matrix cores with every fp32 operand
+split into hi + lo fp16 (22 significant bits) and three MFMAs per product, fp32 accumulation (`--conv-math f16x3`, default;
+measured error vs an fp64 reference 1.5e-6 relative, the fp32 MFMA's is 2.3e-6 -- tests/test_gpu_ops.py); `--conv-math f32`
+runs them on v_mfma_f32_32x32x2_f32 instead.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the implicit-GEMM conv on the matrix cores), `roofline_creff`
 (warp + CReFF stage against the HBM roofline, algorithmic bytes of SURVEY.md section 8d), `cpu_baseline` (the oracle,
 i.e. a port, timed on the host cores for one non-keyframe of the same clip) and `parity` (max-abs error and argmax
 agreement of that frame against the oracle).
@@ -40,6 +45,7 @@ CONFIGS = {
                  label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
@@ -70,6 +76,8 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
+    ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
+                    help="MFMA back end of the fp32 conv GEMMs: f16x3 = split-fp16 emulation (3 fp16 MFMAs, fp32 accumulate), f32 = fp32 MFMA")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -87,6 +95,7 @@ def main():
     from arseg_amd.gop import GopRunner
 
     _lib.load()
+    ops.set_conv_math(args.conv_math)
     cfg = CONFIGS[args.config]
     H, W, N_CLS = cfg["H"], cfg["W"], cfg["n_cls"]
     mean, std = (synth.CAMVID_MEAN, synth.CAMVID_STD) if cfg["kind"] == "psp" else (synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)
@@ -157,8 +166,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "conv_math": args.conv_math + (" (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)" if args.conv_math == "f16x3" else " (fp32 MFMA)"),
         "streams": len(streams),
-        "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32",
+        "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32 tensors",
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
         "all_frames_per_s": world * GOP * args.steps / elapsed,
@@ -188,16 +198,28 @@ def main():
         wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output")) / 3 + \
             sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9          # 2*MACs of every conv/linear of the reference (hook-counted)
+        # f16x3: every GEMM MAC is three fp16 MFMA MACs -> executed matrix-core FLOPs = 3 x the GEMM FLOPs, against the fp16 peak
+        mfma_mult, peak = (3.0, PEAK_F16_MFMA_TFLOPS) if args.conv_math == "f16x3" else (1.0, PEAK_FP32_MFMA_TFLOPS)
+        gemm_tf = tot_flops / (tot_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
+        if os.path.exists(tfile) and args.config == "psp":
+            with open(tfile) as f:
+                traffic = json.load(f).get(args.conv_math, {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
-            "kernel": "conv_igemm_f32_kernel (implicit-GEMM / batched Winograd GEMM, v_mfma_f32_32x32x2_f32)",
-            "bound": "mfma", "achieved": tot_flops / (tot_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tot_flops / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-            "traffic": None,
-            "per_launch": {"avg_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
-            "lr_batch_tflops": tf(conv), "hr_frame_tflops": tf(conv_k),
+            "kernel": "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> (implicit GEMM / batched Winograd GEMM; " +
+                      ("3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)" if args.conv_math == "f16x3" else "v_mfma_f32_32x32x2_f32)"),
+            "bound": "mfma", "achieved": mfma_mult * gemm_tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": mfma_mult * gemm_tf / peak,
+            "traffic": traffic,
+            "fp32_gemm_tflops": gemm_tf, "fp32_gemm_vs_fp32_mfma_peak": gemm_tf / PEAK_FP32_MFMA_TFLOPS,
+            "per_launch": {"avg_gemm_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
+            "lr_batch_gemm_tflops": tf(conv), "hr_frame_gemm_tflops": tf(conv_k),
             "reference_direct_conv_tflops": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12,
-            "note": "achieved = FLOPs executed by the MFMA kernel / its time; reference_direct_conv_tflops = the reference's "
-                    "direct-convolution FLOP count (SURVEY 8d) / (MFMA kernel + Winograd transform time)",
+            "note": "achieved = matrix-core FLOPs executed by the conv kernel (GEMM FLOPs x3 under f16x3) / its time, against the "
+                    "dense MFMA peak of the instruction used; fp32_gemm_tflops = the fp32 GEMM FLOPs it delivers (Winograd and the "
+                    "folded pyramid execute fewer than the reference's direct convs); reference_direct_conv_tflops = the "
+                    "reference's direct-convolution FLOP count (SURVEY 8d) / (conv kernel + Winograd transform time)",
         }
         cre, wrp = nk["creff"], nk["warp_mvq"]
         # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
@@ -207,7 +229,7 @@ def main():
         nb = 3 * len(runner.plan)                                         # frames covered by the profiled launches
         stage_ms = (cre["ms"] + wrp["ms"]) / nb
         result["roofline_creff"] = {
-            "kernel": "warp_mvq_nhwc_kernel + creff_kernel<7,NC,TH> (MV warp + fused CReFF + classifier)",
+            "kernel": "warp_mvq_nhwc_kernel + " + ("creff_mfma_kernel<NB>" if C >= 128 else "creff_kernel<7,NC,TH>") + " (MV warp + fused CReFF + classifier)",
             "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
             "algorithmic_bytes_per_frame": stage_bytes, "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
