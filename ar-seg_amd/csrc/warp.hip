@@ -123,15 +123,18 @@ __global__ __launch_bounds__(256) void mv_resize_kernel(const int16_t *__restric
     }
 }
 
-// grid = (ceil(Wp/16), Hp, N); a block covers 16 pixels of one row, 16 lanes per pixel walk the channel vectors:
-// no 64-bit index division, the four taps of a pixel are read as whole contiguous pixels (C*4 bytes each).
+// grid = (ceil(Wp/64), Hp, N); a block covers 64 pixels of one row.  Phase 1: one lane per pixel does the fp64 coordinate
+// arithmetic (two divisions) and the tap setup and parks the result in LDS -- done by 16 lanes per pixel it would occupy
+// whole waves with 4 useful lanes.  Phase 2: 16 lanes per pixel walk the channel vectors, four pixels groups per thread;
+// the four taps of a pixel are read as whole contiguous pixels (C*4 bytes each), branch-free: taps outside the image get
+// weight 0 and a clamped (in-range) address.
 __global__ __launch_bounds__(256) void warp_mvq_nhwc_kernel(const float *__restrict__ feat, const int16_t *__restrict__ mv,
                                                             float *__restrict__ out, int N, int C, int Hp, int Wp, int H, int W, int c8) {
-    const int sub = threadIdx.x & 15, y = blockIdx.y, n = blockIdx.z;
-    const int x = min(blockIdx.x * 16 + (int)(threadIdx.x >> 4), Wp - 1);      // clamped: surplus lanes redo the last pixel
-    // the fp64 coordinate arithmetic (two divisions) is done by one lane per pixel and broadcast to its 16 lanes
-    float gx = 0.f, gy = 0.f;
-    if (sub == 0) {
+    __shared__ int s_off[4][64];
+    __shared__ float s_w[4][64];
+    const int tid = threadIdx.x, y = blockIdx.y, n = blockIdx.z, xb = blockIdx.x * 64;
+    if (tid < 64) {
+        const int x = min(xb + tid, Wp - 1);                                  // clamped: surplus lanes redo the last pixel
         double fx, fy;
         if (Hp == H && Wp == W) {              // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
             const int16_t *m = mv + ((size_t)n * H * W + (size_t)y * W + x) * 2;
@@ -139,17 +142,34 @@ __global__ __launch_bounds__(256) void warp_mvq_nhwc_kernel(const float *__restr
         } else {
             mv_at(mv + (size_t)n * H * W * 2, H, W, Hp, Wp, y, x, fx, fy);
         }
+        float gx, gy;
         norm_grid<double>(x, y, fx, fy, Hp, Wp, gx, gy);
+        const Taps t = make_taps(gx, gy, Hp, Wp);
+        const int xa = min(max(t.x0, 0), Wp - 1), xc = min(max(t.x0 + 1, 0), Wp - 1);
+        const int ya = min(max(t.y0, 0), Hp - 1), yc = min(max(t.y0 + 1, 0), Hp - 1);
+        s_off[0][tid] = ya * Wp + xa; s_off[1][tid] = ya * Wp + xc; s_off[2][tid] = yc * Wp + xa; s_off[3][tid] = yc * Wp + xc;
+        s_w[0][tid] = t.vy0 && t.vx0 ? t.wnw : 0.f; s_w[1][tid] = t.vy0 && t.vx1 ? t.wne : 0.f;
+        s_w[2][tid] = t.vy1 && t.vx0 ? t.wsw : 0.f; s_w[3][tid] = t.vy1 && t.vx1 ? t.wse : 0.f;
     }
-    gx = __shfl(gx, 0, 16);
-    gy = __shfl(gy, 0, 16);
-    const Taps t = make_taps(gx, gy, Hp, Wp);
+    __syncthreads();
+    const int sub = tid & 15;
     const float *img = feat + (size_t)n * Hp * Wp * C;
-    const int hw = Hp * Wp, pix = y * Wp + x;
-    for (int c = sub * 4; c < C; c += 64) {
-        const f32x4 v = gather4(img, t, Wp, C, c);
-        const size_t o = c8 ? ((((size_t)n * (C >> 3) + (c >> 3)) * hw + pix) * 8 + (c & 4)) : (((size_t)n * hw + pix) * C + c);
-        *reinterpret_cast<f32x4 *>(out + o) = v;        // (duplicate lanes of a clamped pixel store identical values)
+    const int hw = Hp * Wp;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int pl = it * 16 + (tid >> 4);
+        const int x = min(xb + pl, Wp - 1), pix = y * Wp + x;
+        const int o0 = s_off[0][pl], o1 = s_off[1][pl], o2 = s_off[2][pl], o3 = s_off[3][pl];
+        const float w0 = s_w[0][pl], w1 = s_w[1][pl], w2 = s_w[2][pl], w3 = s_w[3][pl];
+        for (int c = sub * 4; c < C; c += 64) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc += *reinterpret_cast<const f32x4 *>(img + (size_t)o0 * C + c) * w0;
+            acc += *reinterpret_cast<const f32x4 *>(img + (size_t)o1 * C + c) * w1;
+            acc += *reinterpret_cast<const f32x4 *>(img + (size_t)o2 * C + c) * w2;
+            acc += *reinterpret_cast<const f32x4 *>(img + (size_t)o3 * C + c) * w3;
+            const size_t o = c8 ? ((((size_t)n * (C >> 3) + (c >> 3)) * hw + pix) * 8 + (c & 4)) : (((size_t)n * hw + pix) * C + c);
+            *reinterpret_cast<f32x4 *>(out + o) = acc;      // (duplicate lanes of a clamped pixel store identical values)
+        }
     }
 }
 
@@ -204,7 +224,7 @@ extern "C" int arseg_warp_mvq_fwd(const float *feature, const int16_t *mv_q, flo
     if (out_layout != ARSEG_NHWC && out_layout != ARSEG_C8) return ARSEG_EINVAL;
     if (out_layout == ARSEG_C8 && (C & 7)) return ARSEG_EINVAL;
     if (Hp > 65535 || N > 65535) return ARSEG_EUNSUPPORTED;
-    hipLaunchKernelGGL(warp_mvq_nhwc_kernel, dim3(arseg_cdiv(Wp, 16), Hp, N), dim3(256), 0, arseg_stream(stream), feature, mv_q, out, N, C,
+    hipLaunchKernelGGL(warp_mvq_nhwc_kernel, dim3(arseg_cdiv(Wp, 64), Hp, N), dim3(256), 0, arseg_stream(stream), feature, mv_q, out, N, C,
                        Hp, Wp, H, W, out_layout == ARSEG_C8 ? 1 : 0);
     return arseg_launch_status();
 }
