@@ -38,6 +38,21 @@ namespace {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Output stores are issued through inline asm: on gfx9 hipcc drains every counter it knows about in front of each s_barrier,
+// so a builtin store exposes the full write latency at the next barrier of the chunk loop.
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+__device__ __forceinline__ void store16_buf(const u32x4 v, const u32x4 rsrc, unsigned voff) {
+    // s_nop: a VMEM store of more than 64 bits needs one wait state before its data VGPRs may be overwritten
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigned voff) {
+    asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+}
+
 constexpr int TW = 32;
 constexpr int G = 2;       // float4 groups per 8-channel chunk
 constexpr int PAD = 4;     // float4 pad between the two group planes (bank spread for paired writes)
@@ -324,8 +339,7 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
     // Bounds-checked buffer stores: lanes outside the image get an offset past num_records and the hardware
     // drops the store -- no divergent branch around the stores (a branch makes LLVM sink the PV FMA chain
     // into it and spill hundreds of VGPRs).
-    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
+    const u32x4 p_rsrc = make_rsrc(p.p_out, p.p_bytes), l_rsrc = make_rsrc(p.logits, p.l_bytes);
 
     // ------------------------------------------------------------------ pass 2: weighted values, residual, head
     for (int cb = 0; cb < CB; ++cb) {
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
             for (int g = 0; g < G; ++g) {
                 const f32x4 o = lrv[j][g] + a[j][g];
                 const unsigned off = (unsigned)((((((size_t)n * CB + cb) * p.Hp + gy) * p.Wp + gx) * 8 + g * 4) * sizeof(float));
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, (j == 0 ? in0 : in1) ? off : 0xFFFFFFF0u, 0, 0);
+                store16_buf(__builtin_bit_cast(u32x4, o), p_rsrc, (j == 0 ? in0 : in1) ? off : 0xFFFFFFF0u);
                 if (NC > 0) {
 #pragma unroll
                     for (int k = 0; k < NCA; ++k) {   // branch-free: class rows past n_cls re-read the last row (LDS broadcast)
@@ -416,7 +430,7 @@ __global__ __launch_bounds__(16 * TH, 2) void creff_kernel(const CreffParams p) 
 #pragma unroll
             for (int k = 0; k < NCA; ++k) {
                 const unsigned off = (unsigned)(((((size_t)n * p.n_cls + k) * p.Hp + py0 + j) * p.Wp + px) * sizeof(float));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[j][k]), l_rsrc, ((j == 0 ? in0 : in1) && k < p.n_cls) ? off : 0xFFFFFFF0u, 0, 0);
+                store4_buf(__float_as_uint(lg[j][k]), l_rsrc, ((j == 0 ? in0 : in1) && k < p.n_cls) ? off : 0xFFFFFFF0u);
             }
         }
     }
