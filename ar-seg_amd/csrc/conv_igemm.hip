@@ -333,6 +333,191 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution with the input patch of a tile resident in LDS (f16x3 only; tile_cfg 13 / 14).
+// The implicit-GEMM kernel above re-stages (and re-splits) the activation slice of every filter tap: nine global loads,
+// nine hi/lo splits and nine LDS writes per input element.  Here a workgroup owns TH x TW = 128 output pixels of one image
+// and, per 32-channel chunk, stages the (TH+2d) x (TW+2d) input patch once, split into [32 hi | 32 lo] halves per pixel;
+// the nine taps are A-fragment *address offsets* into that patch.  K order = (chunk, tap), i.e. K tile kt = tap*Cin/32 +
+// chunk of the ordinary packed weights.  Per tap only the weight tile is streamed (double buffered, one barrier per tap);
+// the next chunk's patch is prefetched into registers under the nine taps of the current one.
+template <int BN, int WM>      // WM wave rows of 64 output pixels each: BM = 64*WM pixels, 2*WM waves
+__global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_kernel(const ConvParams p, int TW, int log2TW) {
+    constexpr int ROWB = 144;                          // bytes per LDS row: 32 hi + 32 lo halves + pad (conflict-free b128 reads)
+    constexpr int NT = 128 * WM, BM = 64 * WM;
+    constexpr int TN = BN / 64, TM = 2, RB = (BN * 8 + NT - 1) / NT, RPB = NT / 8;
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int MAXI = WM == 2 ? 9 : 7;              // patch items (pixel, 16-byte piece) per thread: <= 288 / 448 pixels
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int TH = BM >> log2TW, d = p.dil, PW = TW + 2 * d, PH = TH + 2 * d, npx = PW * PH;
+    unsigned char *Ps = reinterpret_cast<unsigned char *>(smem);               // [npx][ROWB]
+    unsigned char *Bs = Ps + ((npx * ROWB + 255) & ~255);                        // [2][BN][ROWB]
+
+    // tile decode (n fastest over output-channel tiles, then x, y, image), XCD-contiguous like the GEMM kernel
+    const int tiles_x = (p.Wo + TW - 1) >> log2TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nblk = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int img = tile_m / (tiles_x * tiles_y), trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int tid = threadIdx.x;
+
+    // patch items of this thread: item i = (pixel i/8, piece i%8); global byte offset without the chunk term, or OOB
+    unsigned poff[MAXI];
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = tid + it * NT, px = i >> 3, py = px / PW, pxx = px - py * PW;
+        const int gy = ty0 - d + py, gx = tx0 - d + pxx;
+        const bool ok = px < npx && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        poff[it] = ok ? (unsigned)((((img * p.H + gy) * p.W + gx) * p.in_ld) * 4 + (i & 7) * 16) : OOB;
+    }
+    const int chunk = tid & 7, row0 = tid >> 3;
+    unsigned woff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + row0 + RPB * i;
+        woff[i] = (n < p.Cout && row0 + RPB * i < BN) ? (unsigned)(n * p.Kpad + chunk * 4) * 4u : OOB;
+    }
+    const int nchunk = p.Cin >> 5;
+
+    struct BRegs { u32x4 v[RB]; };
+    u32x4 rp[MAXI];
+    auto load_patch = [&](int ck) {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) rp[it] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, poff[it] + (unsigned)(ck * 128), 0, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int i = tid + it * NT, px = i >> 3;
+            if (px < npx) {
+                uint2 hi, lo;
+                split_f16x3(__builtin_bit_cast(f32x4, rp[it]), hi, lo);
+                unsigned char *row = Ps + px * ROWB + (i & 7) * 8;
+                *reinterpret_cast<uint2 *>(row) = hi;
+                *reinterpret_cast<uint2 *>(row + 64) = lo;
+            }
+        }
+    };
+    auto load_b = [&](int ck, int tap, BRegs &r) {
+        const unsigned kt = (unsigned)(tap * nchunk + ck) * 128u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) r.v[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, woff[i] + kt, 0, 0);
+    };
+    auto store_b = [&](int buf, const BRegs &r) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (row0 + RPB * i < BN) *reinterpret_cast<u32x4 *>(Bs + (buf * BN + row0 + RPB * i) * ROWB + chunk * 16) = r.v[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    // A rows of this lane: output pixel m = wm*64 + tm*32 + li of the tile (wm < WM) -> patch pixel (ty, tx) (+ tap offset later)
+    int arow[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = wm * 64 + tm * 32 + li, ty = m >> log2TW, tx = m & (TW - 1);
+        arow[tm] = (ty * PW + tx) * ROWB + lh * 16;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // K steps s = (chunk ck, tap): s = 9*ck + tap.  Weight tiles are requested two steps ahead (two register stages, LDS
+    // double buffer): a step of 12-24 MFMAs is shorter than the L2 latency.
+    const int nsteps = nchunk * 9;
+    BRegs r0, r1;
+    load_patch(0);
+    load_b(0, 0, r0);
+    store_patch();
+    store_b(0, r0);
+    if (nsteps > 1) load_b(0, 1, r0);
+    __syncthreads();
+    int cur = 0, ck = 0, tap = 0;              // of the step being computed
+    int ck2 = 0, tap2 = 2;                     // of the step two ahead (valid while s + 2 < nsteps; 9 taps >= 3)
+    auto step = [&](int s_, BRegs &ld, BRegs &st) {
+        if (s_ + 2 < nsteps) load_b(ck2, tap2, ld);
+        if (tap == 0 && ck + 1 < nchunk) load_patch(ck + 1);
+        const int r3 = (tap * 11) >> 5, s3 = tap - r3 * 3;                 // tap = 3*r3 + s3
+        const int toff = (r3 * d * PW + s3 * d) * ROWB;
+        const unsigned char *bh = Bs + (cur * BN + wn * (BN / 2) + li) * ROWB + lh * 16;
+        // all fragments of the tap first (one exposed LDS latency per tap), then the MFMAs back to back
+        h16x8 fah[2][TM], fal[2][TM], fbh[2][TN], fbl[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) {
+                fah[ks][t] = *reinterpret_cast<const h16x8 *>(Ps + arow[t] + toff + ks * 32);
+                fal[ks][t] = *reinterpret_cast<const h16x8 *>(Ps + arow[t] + toff + 64 + ks * 32);
+            }
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                fbh[ks][t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * ROWB + ks * 32);
+                fbl[ks][t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * ROWB + 64 + ks * 32);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal[ks][tm], fbh[ks][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][tm], fbl[ks][tn], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah[ks][tm], fbh[ks][tn], acc[tm][tn], 0, 0, 0);
+        }
+        if (s_ + 1 < nsteps) store_b(cur ^ 1, st);
+        __syncthreads();
+        cur ^= 1;
+        if (tap == 8 && ck + 1 < nchunk) {     // everybody is past the last tap of this chunk: the patch may be replaced
+            store_patch();
+            __syncthreads();
+        }
+        if (++tap == 9) { tap = 0; ++ck; }
+        if (++tap2 == 9) { tap2 = 0; ++ck2; }
+    };
+#pragma unroll 1
+    for (int s_ = 0; s_ < nsteps; s_ += 2) {
+        step(s_, r1, r0);
+        if (s_ + 1 < nsteps) step(s_ + 1, r0, r1);
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int n = n0 + wn * (BN / 2) + tn * 32 + li;
+            if (n >= p.Cout) continue;
+            const float sc = p.scale ? p.scale[n] : 1.0f, bi = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int oy = ty0 + (ml >> log2TW), ox = tx0 + (ml & (TW - 1));
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                const size_t m = ((size_t)img * p.Ho + oy) * p.Wo + ox;
+                float v = acc[tm][tn][r] * sc + bi;
+                if (p.res) v += p.res[m * p.res_ld + n];
+                p.out[m * p.out_ld + n] = apply_act(v, p.act, p.slope);
+            }
+        }
+}
+
 // sums the split-K partials in slice order and applies the epilogue; 4 channels per thread
 __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParams p) {
     const int c4 = p.Cout >> 2;
@@ -350,7 +535,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const ConvParam
     }
 }
 
-struct Plan { int bm, bn, bk, nbuf, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad; };
+struct Plan { int bm, bn, bk, nbuf, nsplit, ktiles, ktiles_per_split, tiles_m, tiles_n, Ho, Wo, M, K, Kpad, patch_tw; };
 
 int make_plan(const arseg_conv_desc *d, Plan *pl) {
     if (!d) return ARSEG_EINVAL;
@@ -368,7 +553,24 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->M = (int)M;
     pl->K = d->R * d->S * d->Cin;
     pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
-    if (d->tile_cfg < 0 || d->tile_cfg > 12) return ARSEG_EINVAL;
+    if (d->tile_cfg < 0 || d->tile_cfg > 16) return ARSEG_EINVAL;
+    pl->patch_tw = 0;
+    if (d->tile_cfg >= 13) {          // patch-resident 3x3 kernel: 128 (13, 14) / 256 (15, 16) pixel tiles TH x TW of one image, BN = 64 / 128
+        if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || d->math != ARSEG_MATH_F16X3 || (d->Cin & 31) || d->batch > 1 ||
+            d->split_k > 1)
+            return ARSEG_EUNSUPPORTED;
+        const int bm = d->tile_cfg >= 15 ? 256 : 128;
+        const int tw = pl->Wo >= 48 ? 64 : (pl->Wo >= 24 ? 32 : 16), th = bm / tw;
+        if ((th + 2 * d->dil) * (tw + 2 * d->dil) > (bm == 128 ? 288 : 448)) return ARSEG_EUNSUPPORTED;
+        if (((long long)d->N * d->H * d->W * d->in_ld + d->Cin) * 4 >= (1ll << 31) || (long long)d->Cout * pl->Kpad * 4 >= (1ll << 31))
+            return ARSEG_EUNSUPPORTED;
+        pl->patch_tw = tw;
+        pl->bm = bm; pl->bn = (d->tile_cfg & 1) ? 64 : 128; pl->bk = 32; pl->nbuf = 2;
+        pl->ktiles = pl->Kpad / 32; pl->ktiles_per_split = pl->ktiles; pl->nsplit = 1;
+        pl->tiles_m = d->N * arseg_cdiv(pl->Ho, th) * arseg_cdiv(pl->Wo, tw);
+        pl->tiles_n = arseg_cdiv(d->Cout, pl->bn);
+        return ARSEG_OK;
+    }
     pl->bk = d->tile_cfg >= 9 ? 64 : 32;
     pl->ktiles = (pl->Kpad + pl->bk - 1) / pl->bk;
     // operands are addressed through 32-bit buffer offsets
@@ -443,6 +645,22 @@ int launch_tile(const ConvParams &p, const Plan &pl, hipStream_t hs) {
     return launch<64, 64, BK, NBUF, MATH>(p, pl, hs);
 }
 
+template <int BN, int WM>
+int launch_patch(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
+    const int tw = pl.patch_tw, th = 64 * WM / tw, npx = (th + 2 * dil) * (tw + 2 * dil);
+    const size_t smem = (size_t)((npx * 144 + 255) & ~255) + (size_t)2 * BN * 144;
+    static size_t attr_smem = 0;     // grow-only; a race only repeats the same call
+    if (smem > attr_smem) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<BN, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_smem = smem;
+    }
+    int l2 = 0;
+    while ((1 << l2) < tw) ++l2;
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM>), dim3(pl.tiles_m * pl.tiles_n), dim3(128 * WM), smem, st, p, tw, l2);
+    return arseg_launch_status();
+}
+
 template <int MATH>
 int launch_math(const ConvParams &p, const Plan &pl, hipStream_t hs) {
     if (pl.bk == 64) return launch_tile<64, 1, MATH>(p, pl, hs);
@@ -504,6 +722,11 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.out_bs = d->batch > 1 ? d->out_batch_stride : 0;
     if (d->batch > 1 && (residual || d->batch > 65535 || (d->in_batch_stride & 3) || (d->w_batch_stride & 3))) return ARSEG_EINVAL;
     hipStream_t hs = arseg_stream(stream);
+    if (pl.patch_tw) {
+        p.in_bytes = (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);
+        if (pl.bm == 256) return pl.bn == 64 ? launch_patch<64, 4>(p, pl, d->dil, hs) : launch_patch<128, 4>(p, pl, d->dil, hs);
+        return pl.bn == 64 ? launch_patch<64, 2>(p, pl, d->dil, hs) : launch_patch<128, 2>(p, pl, d->dil, hs);
+    }
     st = d->math == ARSEG_MATH_F16X3 ? launch_math<ARSEG_MATH_F16X3>(p, pl, hs) : launch_math<ARSEG_MATH_F32>(p, pl, hs);
     if (st != ARSEG_OK) return st;
     if (pl.nsplit > 1) {

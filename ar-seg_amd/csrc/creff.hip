@@ -46,8 +46,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
                  (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
 }
 __device__ __forceinline__ void store16_buf(const u32x4 v, const u32x4 rsrc, unsigned voff) {
-    // s_nop: a VMEM store of more than 64 bits needs one wait state before its data VGPRs may be overwritten
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+    // s_nop: a VMEM store of more than 64 bits needs two wait states (gfx940+) before its data VGPRs may be overwritten
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigned voff) {
     asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");

@@ -82,9 +82,9 @@ __device__ __forceinline__ void dma16_glb(const void *g, unsigned lds_base) {
                  : "=&s"(keep) : "s"(lds_base), "v"(g) : "memory");
 }
 __device__ __forceinline__ void store16_buf(const u32x4 v, const u32x4 rsrc, unsigned voff) {
-    // s_nop: a VMEM store of more than 64 bits needs one wait state before its data VGPRs may be overwritten (the
+    // s_nop: a VMEM store of more than 64 bits needs two wait states (gfx940+) before its data VGPRs may be overwritten (the
     // compiler pads this hazard for its own stores, not inside asm)
-    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigned voff) {
     asm volatile("buffer_store_dword %0, %1, %2, 0 offen" ::"v"(v), "v"(voff), "s"(rsrc) : "memory");

@@ -329,8 +329,10 @@ class _PlanCache(dict):
 _conv_plans = _PlanCache()
 
 
-def _conv_candidates(ktiles: int, cout: int, m: int):
+def _conv_candidates(ktiles: int, cout: int, m: int, patch_ok: bool = False):
     cands = []
+    if patch_ok:                                   # patch-resident 3x3 kernel (13/14: 128-pixel tiles, 15/16: 256; BN 64/128)
+        cands += [(15, 1), (13, 1)] + ([(16, 1), (14, 1)] if cout > 64 else [])
     for cfg in (5, 6, 7, 8, 9, 10, 11, 12):
         bn = 128 if cfg in (5, 8, 9, 12) else 64
         bm = 128 if cfg in (5, 6, 9, 10) else 64
@@ -482,7 +484,8 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
 def _tune_conv(launch, pc, m):
     ktiles = (pc.R * pc.S * pc.cin_pad + 31) // 32
     best, best_t = (0, 0), float("inf")
-    for cfg, sk in [(0, 0)] + _conv_candidates(ktiles, pc.cout, m):
+    patch_ok = (_math == _lib.MATH_F16X3 and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == pc.dil == 1 and pc.cin_pad % 32 == 0)
+    for cfg, sk in [(0, 0)] + _conv_candidates(ktiles, pc.cout, m, patch_ok):
         try:
             launch(cfg, sk, record=False)                          # warm (also sizes the workspace)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

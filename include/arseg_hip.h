@@ -119,7 +119,10 @@ typedef struct arseg_conv_desc {
     int act;           /* enum arseg_act */
     float prelu_slope; /* single shared slope (nn.PReLU() default, model/pspnet.py:40) */
     int tile_cfg;      /* 0 auto; 1..4 = 128x128, 128x64, 64x64, 64x128 (K step 32) with a double-buffered LDS tile; 5..8 = the
-                          same tiles single-buffered (half the LDS, more workgroups per CU); 9..12 = single-buffered, K step 64 */
+                          same tiles single-buffered (half the LDS, more workgroups per CU); 9..12 = single-buffered, K step 64;
+                          13..16 = patch-resident kernel for 3x3 stride-1 pad==dil convs under ARSEG_MATH_F16X3 (Cin % 32 == 0): the
+                          input patch of a 128- (13, 14) or 256-pixel (15, 16) tile stays in LDS for all nine taps, BN = 64 / 128;
+                          ARSEG_EUNSUPPORTED for other shapes */
     int split_k;       /* 0 auto, >= 1 explicit */
     /* batched mode (used by the Winograd path): `batch` independent problems of identical shape, problem b reads
        in + b*in_batch_stride, w_packed + b*w_batch_stride and writes out + b*out_batch_stride (strides in floats);
