@@ -39,11 +39,11 @@ for key, pat in (("fetch", "fetch"), ("write", "write")):
         k = short(r["Kernel_Name"]); agg[k][0] += 1; agg[k][1] += float(r["Counter_Value"])
     for k, (n, v) in agg.items():
         res["kernels"].setdefault(k, {})[f"{key}_kib_avg"] = v / n; res["kernels"][k]["launches"] = n
-conv = [v for k, v in res["kernels"].items() if k.startswith("conv_igemm_kernel")]
+conv = [v for k, v in res["kernels"].items() if k.startswith("conv_igemm_kernel") or k.startswith("conv3x3_patch_kernel")]
 if conv:
     n = sum(v["launches"] for v in conv)
     fetch = sum(v.get("fetch_kib_avg", 0) * v["launches"] for v in conv) / n; write = sum(v.get("write_kib_avg", 0) * v["launches"] for v in conv) / n
-    res["conv_igemm_all_tiles"] = {"launches": n, "fetch_kib_avg": fetch, "write_kib_avg": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024}
+    res["conv_all_tiles"] = {"launches": n, "fetch_kib_avg": fetch, "write_kib_avg": write, "hbm_bytes_per_launch": (2 * fetch + write) * 1024}
 json.dump(res, open(f"{out}/{tag}_pmc_hbm.json", "w"), indent=1)
 print(open(f"{out}/{tag}_bench.json").read()[:600])
 PY
