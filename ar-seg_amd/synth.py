@@ -162,11 +162,12 @@ def make_clip(seed: int, H: int, W: int, gop: int = 12, mean=CAMVID_MEAN, std=CA
 # (model/bisenet.py:428-430, 490-492): ``feat_conv_out`` is ``conv_out.conv`` and ``final_conv`` is
 # ``conv_out.conv_out``.  A state_dict therefore lists every such tensor under two keys;
 # ``load_state_dict`` copies in key order, so the value under the LATER key (the alias) wins.
-BISENET_ALIASES = (("feat_conv_out.", "conv_out.conv."), ("final_conv.", "conv_out.conv_out."))
+BISENET_ALIASES = (("feat_conv_out.", "conv_out.conv."), ("final_conv.", "conv_out.conv_out."),
+                   ("final_conv.", "cls.4."))          # last pair: pspnet_semseg.PSPNetWithFuse.final_conv = cls[-1]
 
 
 def resolve_aliases(sd):
-    """Return a copy of ``sd`` in which aliased BiSeNet keys hold the value load_state_dict would leave."""
+    """Return a copy of ``sd`` in which aliased keys (BiSeNet, Cityscapes PSPNet) hold the value load_state_dict would leave."""
     out = type(sd)(sd)
     for alias, canon in BISENET_ALIASES:
         for k in list(sd.keys()):

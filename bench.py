@@ -44,6 +44,8 @@ CONFIGS = {
                 label="PSPNet-18 HR keyframe 512x1024 + 11 non-keyframes LR 0.5x (256x512) + CReFF 7x7 @512x1024"),
     "psp2k": dict(kind="psp", H=1024, W=2048, n_cls=12, C=64, feat_div=1, ref_lr_gflop=467.5, ref_hr_gflop=1872.8,
                   label="PSPNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @1024x2048"),
+    "semseg": dict(kind="semseg", H=1024, W=2048, n_cls=19, C=512, feat_div=8, ref_lr_gflop=0.0, ref_hr_gflop=0.0,
+                   label="Cityscapes PSPNet-18 (model/pspnet_semseg.py) HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 C=512 @128x256"),
     "bise": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=60.6, ref_hr_gflop=242.8,
                  label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256"),
 }
@@ -54,10 +56,13 @@ PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6
 
 def build_nets(dev, cfg):
     from arseg_amd import synth
-    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse, PSPNet, PSPNetWithFuse
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse, PSPNet, PSPNetWithFuse, pspnet_semseg
 
     N_CLS = cfg["n_cls"]
-    if cfg["kind"] == "psp":
+    if cfg["kind"] == "semseg":
+        hr = pspnet_semseg.PSPNetWithFuse(bins=(1, 2, 3, 6), classes=N_CLS, feat_dim=512, layers=18)      # evaluation.py:27,34: both
+        lr = pspnet_semseg.PSPNetWithFuse(bins=(1, 2, 3, 6), classes=N_CLS, feat_dim=512, layers=18)      # branches use this class
+    elif cfg["kind"] == "psp":
         hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18")
         lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=N_CLS, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
     else:
@@ -164,6 +169,7 @@ def main():
     result = {
         "metric": {"psp": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
                    "psp2k": "non-keyframe frames/sec (backbone+CReFF), PSPNet-18 1024x2048 / LR 512x1024",
+                   "semseg": "non-keyframe frames/sec (backbone+CReFF), Cityscapes PSPNet-18 1024x2048 / LR 512x1024",
                    "bise": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024"}[args.config],
         "value": nonkey_per_step * args.steps / elapsed,
         "unit": "frames/s",
@@ -230,7 +236,8 @@ def main():
         # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
         C, fd = cfg["C"], cfg["feat_div"]
         Hp, Wp = H // fd, W // fd
-        stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * H * W
+        logit_px = Hp * Wp if cfg["kind"] == "semseg" else H * W              # pspnet_semseg phase 2 returns logits at feature resolution
+        stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
         nb = 3 * len(runner.plan)                                         # frames covered by the profiled launches
         stage_ms = (cre["ms"] + wrp["ms"]) / nb
         result["roofline_creff"] = {
@@ -257,7 +264,7 @@ def main():
         with torch.no_grad():
             from arseg_amd.synth import resolve_aliases
             sd_hr, sd_lr = resolve_aliases(sd_hr), resolve_aliases(sd_lr)
-            fwd = cpu_ref.pspnet_forward if cfg["kind"] == "psp" else cpu_ref.bisenet_forward
+            fwd = {"psp": cpu_ref.pspnet_forward, "bise": cpu_ref.bisenet_forward, "semseg": cpu_ref.semseg_forward}[cfg["kind"]]
             ref_cpu = fwd(sd_hr, key)[-1]                                         # outside the timed sample
             t1 = time.perf_counter()
             o_out, o_p, _, _ = cpu_ref.alter_res_step(cfg["kind"], sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)

@@ -248,6 +248,56 @@ def pspnet_fuse_phase2(sd: SD, p: torch.Tensor, ref_p: torch.Tensor, k: int = 7)
 
 
 # ----------------------------------------------------------------------------------------------
+# f1  PSPNet-18 (Cityscapes)                                        model/pspnet_semseg.py:12-250
+# ----------------------------------------------------------------------------------------------
+def _basic_block_semseg(sd: SD, p: str, x: torch.Tensor, stride: int, dil1: int, dil2: int) -> torch.Tensor:
+    """extractors.BasicBlock whose conv2 was re-dilated after construction (pspnet_semseg.py:59-68): conv1 keeps the
+    extractor's dilation (1 in the first block of a layer, the layer's in the second), conv2 gets the layer's."""
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, dil1, dil1)))
+    out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, 1, dil2, dil2))
+    res = x
+    if (p + ".downsample.0.weight") in sd:
+        res = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride))
+    return F.relu(out + res)
+
+
+def semseg_phase1(sd: SD, x: torch.Tensor, bins=(1, 2, 3, 6)):
+    """PSPNetWithFuse.forward_phase1 (pspnet_semseg.py:219-231): -> (x_tmp = layer3 output, p = cls[:-1](ppm(layer4)))."""
+    x = F.relu(_bn(sd, "layer0.1", _conv(sd, "layer0.0", x, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for name, stride, dil in (("layer1", 1, 1), ("layer2", 2, 1), ("layer3", 1, 2), ("layer4", 1, 4)):
+        x = _basic_block_semseg(sd, f"{name}.0", x, stride, 1, dil if name in ("layer3", "layer4") else 1)
+        x = _basic_block_semseg(sd, f"{name}.1", x, 1, dil, dil)
+        if name == "layer3":
+            x_tmp = x
+    out = [x]
+    for i, b in enumerate(bins):                                                        # PPM.forward (:24-30)
+        t = F.adaptive_avg_pool2d(x, b)
+        t = F.relu(_bn(sd, f"ppm.features.{i}.2", _conv(sd, f"ppm.features.{i}.1", t)))
+        out.append(F.interpolate(t, x.shape[2:], mode="bilinear", align_corners=True))
+    p = F.relu(_bn(sd, "cls.1", _conv(sd, "cls.0", torch.cat(out, 1), 1, 1)))           # cls[:-1]; Dropout2d = identity
+    return x_tmp, p
+
+
+def semseg_forward(sd: SD, x: torch.Tensor, bins=(1, 2, 3, 6), zoom_factor: int = 8):
+    """PSPNetWithFuse.forward(x, mode='normal') (pspnet_semseg.py:186-217): (logits, aux logits, p); PSPNet.forward is [0]."""
+    h, w = x.shape[2:]
+    x_tmp, p = semseg_phase1(sd, x, bins)
+    out = _conv(sd, "cls.4", p)
+    aux = _conv(sd, "aux.4", F.relu(_bn(sd, "aux.1", _conv(sd, "aux.0", x_tmp, 1, 1))))
+    if zoom_factor != 1:
+        out = F.interpolate(out, size=(h, w), mode="bilinear", align_corners=True)
+        aux = F.interpolate(aux, size=(h, w), mode="bilinear", align_corners=True)
+    return out, aux, p
+
+
+def semseg_phase2(sd: SD, p: torch.Tensor, ref_p: torch.Tensor, k: int = 7):
+    """PSPNetWithFuse.forward_phase2 (pspnet_semseg.py:233-247): raw logits at feature resolution, fused feature."""
+    p = my_attention(sd, "fuse_attention.", ref_p, p, k, k)
+    return _conv(sd, "final_conv", p), p
+
+
+# ----------------------------------------------------------------------------------------------
 # a13-a21  BiSeNetV1-18                                                    model/bisenet.py
 # ----------------------------------------------------------------------------------------------
 def _cbr(sd: SD, p: str, x: torch.Tensor, stride=1, padding=1) -> torch.Tensor:
@@ -378,9 +428,10 @@ def miou(hist: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 def alter_res_step(kind: str, sd_hr: SD, sd_lr: SD, img: torch.Tensor, ref_img: torch.Tensor, flow: torch.Tensor,
                    scale: float = 0.5, ref_p: torch.Tensor | None = None):
-    """kind: 'psp' | 'bise'.  flow: [1,H,W,2] float64 pixels.  Returns (logits, p, ref_p_warped, ref_p)."""
+    """kind: 'psp' | 'bise' | 'semseg'.  flow: [1,H,W,2] float64 pixels.  Returns (logits, p, ref_p_warped, ref_p)."""
     if ref_p is None:
-        ref_p = (pspnet_forward(sd_hr, ref_img) if kind == "psp" else bisenet_forward(sd_hr, ref_img))[-1]   # :173-174
+        fwd = {"psp": pspnet_forward, "bise": bisenet_forward, "semseg": semseg_forward}[kind]
+        ref_p = fwd(sd_hr, ref_img)[-1]                                                                        # :173-174
     Hp, Wp = ref_p.shape[-2:]
     f = mv_resize(flow, Hp, Wp)                                                                               # :177-180
     warped = warp_feature(ref_p, f)                                                                           # :183
@@ -388,6 +439,9 @@ def alter_res_step(kind: str, sd_hr: SD, sd_lr: SD, img: torch.Tensor, ref_img: 
     if kind == "psp":
         out_p = pspnet_fuse_phase1(sd_lr, lr)[-1]
         out, p = pspnet_fuse_phase2(sd_lr, out_p, warped)
+    elif kind == "semseg":
+        out_p = semseg_phase1(sd_lr, lr)[-1]
+        out, p = semseg_phase2(sd_lr, out_p, warped)
     else:
         out_p = bisenet_fuse_phase1(sd_lr, lr)[-1]
         out, p = bisenet_fuse_phase2(sd_lr, out_p, warped)

@@ -118,8 +118,39 @@ def rnd(seed, *shape, scale=1.0):
     return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
 
 
+def gen_g8(manifest):
+    """G8: Cityscapes PSPNet-18 (model/pspnet_semseg.py)."""
+    semseg = importlib.import_module("model.pspnet_semseg")
+    with torch.no_grad():
+        print("G8 pspnet_semseg")
+        hr_net = semseg.PSPNetWithFuse(bins=(1, 2, 3, 6), classes=19, feat_dim=512, layers=18, pretrained=False).eval()
+        synth.load_synth_weights(hr_net, 4)
+        manifest["SemsegPSPNetWithFuse"] = sd_manifest(hr_net)
+        x = rnd(900, 1, 3, 64, 96)
+        out, aux, p_hr = hr_net(x)                                   # mode='normal': the HR / keyframe branch
+        lr_net = semseg.PSPNetWithFuse(bins=(1, 2, 3, 6), classes=19, feat_dim=512, layers=18, pretrained=False).eval()
+        synth.load_synth_weights(lr_net, 5)
+        xl = rnd(901, 1, 3, 32, 48)
+        x_tmp, p1 = lr_net.forward_phase1(xl)
+        out2, p2 = lr_net.forward_phase2(p1, p_hr)
+        outm, auxm, pm = lr_net(xl, mode="merge", ref_p=p_hr)
+        plain = semseg.PSPNet(bins=(1, 2, 3, 6), classes=19, feat_dim=512, layers=18, pretrained=False).eval()
+        synth.load_synth_weights(plain, 6)
+        manifest["SemsegPSPNet"] = sd_manifest(plain)
+        (outp,) = plain(x)
+        save("g8_semseg", x=x, out=out, aux=aux, p=p_hr, xl=xl, x_tmp1=x_tmp, p1=p1, out2=out2, p2=p2, aux_merge=auxm,
+             merge_equal=np.array([torch.equal(outm, out2), torch.equal(pm, p2)]), out_plain=outp)
+
+
 def main():
     install_shims()
+    if "--only-g8" in sys.argv:                 # added after the first batch: leaves the other vectors untouched
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_g8(manifest)
+        with open(os.path.join(HERE, "manifest.json"), "w") as f:
+            json.dump(manifest, f, indent=0, sort_keys=True)
+        return
     attention = importlib.import_module("model.attention")
     pspnet = importlib.import_module("model.pspnet")
     bisenet = importlib.import_module("model.bisenet")
@@ -262,6 +293,7 @@ def main():
             miou_c = evaluation.EvalConstRes(scale=1.0)(Wrap(hr_m), [(ref, label, None)], 12)
             manifest[f"g7_{kind}_miou_const"] = float(miou_c)
 
+    gen_g8(manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("done")

@@ -74,6 +74,38 @@ def test_pspnet_with_fuse_golden(dev, golden, manifest):
         assert maxdiff(outm, g["out2"]) <= TOL and maxdiff(clsm, g["cls1"]) <= TOL
 
 
+def _semseg(manifest, dev, seed, fuse=True):
+    from arseg_amd import synth
+    from arseg_amd.model import pspnet_semseg
+
+    cls = pspnet_semseg.PSPNetWithFuse if fuse else pspnet_semseg.PSPNet
+    name = "SemsegPSPNetWithFuse" if fuse else "SemsegPSPNet"
+    m = cls(bins=(1, 2, 3, 6), classes=19, feat_dim=512, layers=18)
+    spec = [(k, tuple(s)) for k, s in manifest[name]["keys"]]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed).items()})
+    return m.to(dev).eval()
+
+
+def test_pspnet_semseg_golden(dev, golden, manifest):
+    """Cityscapes PSPNet-18: HR branch, phase 1, phase 2 (CReFF at C=512 on the matrix-core kernel) and
+    the 'merge' mode against vectors produced by the reference's model/pspnet_semseg.py."""
+    g = golden("g8_semseg")
+    hr, lr = _semseg(manifest, dev, 4), _semseg(manifest, dev, 5)
+    with torch.no_grad():
+        out, aux, p = hr(t(g["x"]).to(dev))
+        assert out.shape == g["out"].shape and aux.shape == g["aux"].shape and p.shape == g["p"].shape
+        assert maxdiff(out, g["out"]) <= TOL and maxdiff(aux, g["aux"]) <= TOL and maxdiff(p, g["p"]) <= TOL
+        x_tmp, p1 = lr.forward_phase1(t(g["xl"]).to(dev))
+        assert maxdiff(x_tmp, g["x_tmp1"]) <= TOL and maxdiff(p1, g["p1"]) <= TOL
+        out2, p2 = lr.forward_phase2(t(g["p1"]).to(dev), t(g["p"]).to(dev))
+        assert out2.shape == g["out2"].shape
+        assert maxdiff(out2, g["out2"]) <= TOL and maxdiff(p2, g["p2"]) <= TOL
+        outm, auxm, pm = lr(t(g["xl"]).to(dev), mode="merge", ref_p=p)                 # ref_p as the HR net returned it
+        assert maxdiff(outm, g["out2"]) <= TOL and maxdiff(auxm, g["aux_merge"]) <= TOL and maxdiff(pm, g["p2"]) <= TOL
+        (outp,) = _semseg(manifest, dev, 6, fuse=False)(t(g["x"]).to(dev))
+        assert maxdiff(outp, g["out_plain"]) <= TOL
+
+
 def test_bisenet_golden(dev, golden, manifest):
     g = golden("g6_bisenet")
     net = _bise(manifest, dev, False)

@@ -89,6 +89,23 @@ def test_g5_pspnet_with_fuse(golden, manifest):
     assert bool(g["merge_equal"].all())
 
 
+def test_g8_pspnet_semseg(golden, manifest):
+    """Cityscapes PSPNet-18 (model/pspnet_semseg.py): the same state_dict spec serves all three nets (seeds 4, 5, 6)."""
+    g = golden("g8_semseg")
+    sd_hr = sd_from_manifest(manifest, "SemsegPSPNetWithFuse", 4)
+    out, aux, p = cpu_ref.semseg_forward(sd_hr, t(g["x"]))
+    assert maxdiff(out, g["out"]) <= 5e-5 and maxdiff(aux, g["aux"]) <= 5e-5 and maxdiff(p, g["p"]) <= 5e-5
+    sd_lr = sd_from_manifest(manifest, "SemsegPSPNetWithFuse", 5)
+    x_tmp, p1 = cpu_ref.semseg_phase1(sd_lr, t(g["xl"]))
+    assert maxdiff(x_tmp, g["x_tmp1"]) <= 5e-5 and maxdiff(p1, g["p1"]) <= 5e-5
+    out2, p2 = cpu_ref.semseg_phase2(sd_lr, t(g["p1"]), t(g["p"]))
+    assert maxdiff(out2, g["out2"]) <= 5e-5 and maxdiff(p2, g["p2"]) <= 5e-5
+    assert maxdiff(cpu_ref.semseg_forward(sd_lr, t(g["xl"]))[1], g["aux_merge"]) <= 5e-5
+    assert bool(g["merge_equal"].all())
+    sd_plain = sd_from_manifest(manifest, "SemsegPSPNet", 6)
+    assert maxdiff(cpu_ref.semseg_forward(sd_plain, t(g["x"]))[0], g["out_plain"]) <= 5e-5
+
+
 def test_g6_bisenet(golden, manifest):
     g = golden("g6_bisenet")
     sd = sd_from_manifest(manifest, "BiSeNetV1", 2)
