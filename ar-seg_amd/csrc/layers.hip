@@ -256,6 +256,36 @@ __global__ __launch_bounds__(256) void frame_to_nhwc4_kernel(const float *__rest
     }
 }
 
+// decoded uint8 HWC frame -> normalised NHWC4 (+ downscale): ToTensor (x/255), Normalize ((x-mean)/std) -- dataset/camvid.py:
+// 503-506, dataset/cityscapes.py:208-214 -- and the evaluator's bilinear(align_corners=True) downscale (evaluation.py:186-188)
+// in one pass, each tap normalised with the reference's fp32 operation order before it is blended.
+__global__ __launch_bounds__(256) void frame_u8_to_nhwc4_kernel(const uint8_t *__restrict__ img, float *__restrict__ out, int N, int H,
+                                                                int W, int h, int w, float m0, float m1, float m2, float s0, float s1, float s2) {
+    const long long total = (long long)N * h * w;
+    const float sy = arseg_resize_scale(H, h, true), sx = arseg_resize_scale(W, w, true);
+    const bool same = (h == H && w == W);
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(pix % w), oy = (int)((pix / w) % h), n = (int)(pix / ((long long)w * h));
+        const uint8_t *base = img + (size_t)n * H * W * 3;
+        auto px = [&](int y, int x, int c) { return ((float)base[((size_t)y * W + x) * 3 + c] / 255.0f - mean[c]) / sd[c]; };
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (same) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = px(oy, ox, c);
+        } else {
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(sy, oy, true, H, y0, y1, ly);
+            arseg_src_index(sx, ox, true, W, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[c] = (1.f - ly) * ((1.f - lx) * px(y0, x0, c) + lx * px(y0, x1, c)) + ly * ((1.f - lx) * px(y1, x0, c) + lx * px(y1, x1, c));
+        }
+        *reinterpret_cast<f32x4 *>(out + pix * 4) = v;
+    }
+}
+
 // ------------------------------------------------------------------ layout changes (LDS-tiled 32x32 transposes)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW,
                                                            int out_ld) {
@@ -425,6 +455,16 @@ extern "C" int arseg_head_fwd(const float *p, int p_ld, const float *wf, const f
 extern "C" int arseg_frame_to_nhwc4_fwd(const float *img, float *out, int N, int H, int W, int h, int w, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(img); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w);
     hipLaunchKernelGGL(frame_to_nhwc4_kernel, dim3(grid_for((long long)N * h * w)), dim3(256), 0, arseg_stream(stream), img, out, N, H, W, h, w);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_frame_u8_to_nhwc4_fwd(const uint8_t *img_hwc, float *out, int N, int H, int W, int h, int w, const float *mean3,
+                                           const float *std3, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(img_hwc); ARSEG_CHECK_PTR(out); ARSEG_CHECK_PTR(mean3); ARSEG_CHECK_PTR(std3);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w);
+    if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return ARSEG_EINVAL;
+    hipLaunchKernelGGL(frame_u8_to_nhwc4_kernel, dim3(grid_for((long long)N * h * w)), dim3(256), 0, arseg_stream(stream), img_hwc, out, N, H,
+                       W, h, w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
     return arseg_launch_status();
 }
 

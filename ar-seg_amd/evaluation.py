@@ -81,20 +81,35 @@ def _miou(hist, n_classes):
 
 
 class EvalAlterRes(object):
-    """evaluation.py:148-215: keyframe through the HR net, non-keyframe through the LR net + CReFF."""
+    """evaluation.py:148-215: keyframe through the HR net, non-keyframe through the LR net + CReFF.
 
-    def __init__(self, scale=0.5, ignore_label=255):
+    ``cache_keyframe`` (extension): the reference recomputes the HR forward of the keyframe for
+    every sample (evaluation.py:173) although the 11 non-keyframes of a GOP share it; with the flag set the keyframe feature is
+    kept while consecutive samples carry the same reference frame (compared on the GPU).  The result is unchanged -- the HR
+    forward is deterministic -- only ~10/11 of the HR forwards disappear when the loader is GOP ordered.  ``hr_forwards``
+    counts the ones executed."""
+
+    def __init__(self, scale=0.5, ignore_label=255, cache_keyframe=False):
         self.ignore_label = ignore_label
         self.scale = scale
+        self.cache_keyframe = cache_keyframe
+        self.hr_forwards = 0
 
     def __call__(self, highres_net, net, dl, n_classes):
         hist = None
         lr_net = _unwrap(net)
+        last_ref, last_p = None, None
         for imgs, label, _, ref_imgs, flow in dl:
             label = label.cuda()
             imgs = imgs.cuda()
             flow = flow.cuda()
-            highres_ref_p = highres_net(ref_imgs.cuda())[-1]                                  # :173-174
+            ref_imgs = ref_imgs.cuda()
+            if self.cache_keyframe and last_ref is not None and last_ref.shape == ref_imgs.shape and torch.equal(last_ref, ref_imgs):
+                highres_ref_p = last_p
+            else:
+                highres_ref_p = highres_net(ref_imgs)[-1]                                     # :173-174
+                self.hr_forwards += 1
+                last_ref, last_p = ref_imgs, highres_ref_p
             flow = resize_flow(flow, highres_ref_p.shape[-2], highres_ref_p.shape[-1])       # :177-180
             highres_ref_p = warpFeature(highres_ref_p, flow)                                 # :183
             N, C, H, W = imgs.shape

@@ -606,6 +606,19 @@ def frame_to_nhwc4(img: torch.Tensor, h: int, w: int) -> torch.Tensor:
     return out
 
 
+def frame_u8_to_nhwc4(img_u8: torch.Tensor, h: int, w: int, mean, std) -> torch.Tensor:
+    """Decoded uint8 frames [N,H,W,3] (HWC, on the GPU) -> normalised NHWC4 [N,h,w,4] (ToTensor + Normalize + bilinear
+    align_corners=True downscale in one kernel; the float frame is never materialised)."""
+    if img_u8.dtype != torch.uint8 or not img_u8.is_cuda or img_u8.dim() != 4 or img_u8.shape[-1] != 3:
+        raise _lib.ArsegError("frame_u8_to_nhwc4 expects a CUDA uint8 tensor [N,H,W,3]")
+    img_u8 = img_u8.contiguous()
+    N, H, W, _ = img_u8.shape
+    out = torch.empty((N, h, w, 4), dtype=torch.float32, device=img_u8.device)
+    m3, s3 = (ctypes.c_float * 3)(*[float(v) for v in mean]), (ctypes.c_float * 3)(*[float(v) for v in std])
+    _launch("frame_u8_to_nhwc4", _lib.load().arseg_frame_u8_to_nhwc4_fwd, _ptr(img_u8), _ptr(out), N, H, W, h, w, m3, s3, _stream())
+    return out
+
+
 def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int, W: int, hist: Optional[torch.Tensor] = None,
                      ignore_label: int = 255, want_pred: bool = True):
     """Evaluator tail (evaluation.py:201-209): returns (pred int32 [N,H,W] or None, hist int64 [n_cls,n_cls] or None)."""

@@ -209,6 +209,11 @@ int arseg_head_fwd(const float *p, int p_ld, const float *wf, const float *bf, f
 /* decoded frame NCHW [N,3,H,W] -> NHWC4 [N,h,w,4] (4th channel 0), bilinear align_corners=True when (h,w) != (H,W)
  * evaluation.py:115-117,186-188 fused with the layout change the conv engine wants */
 int arseg_frame_to_nhwc4_fwd(const float *img, float *out, int N, int H, int W, int h, int w, arseg_stream_t stream);
+/* Decoded uint8 HWC frame(s) [N,H,W,3] (device) -> normalised NHWC4 at (h,w): ToTensor + Normalize(mean, std)
+ * (dataset/camvid.py:503-506, dataset/cityscapes.py:208-214) + the evaluator's bilinear align_corners=True downscale
+ * (evaluation.py:186-188) in one pass.  mean3 / std3: host pointers to 3 floats. */
+int arseg_frame_u8_to_nhwc4_fwd(const uint8_t *img_hwc, float *out, int N, int H, int W, int h, int w, const float *mean3,
+                                const float *std3, arseg_stream_t stream);
 /* layout changes at the API boundary */
 int arseg_nchw_to_nhwc_fwd(const float *in, float *out, int N, int C, int HW, int out_ld, arseg_stream_t stream);
 int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);

@@ -85,6 +85,15 @@ def mv_from_int16(mv_q: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # a3  decoded-frame downscale                                   evaluation.py:115-117,186-188
 # ----------------------------------------------------------------------------------------------
+def to_tensor_normalize(img_u8_hwc, mean, std) -> torch.Tensor:
+    """transforms.ToTensor() + transforms.Normalize(mean, std) (dataset/camvid.py:503-506) restated with torch ops (torchvision
+    is not installed here): uint8 HWC -> float CHW / 255, then (x - mean) / std per channel, fp32.  [N,H,W,3] -> [N,3,H,W]."""
+    x = torch.as_tensor(img_u8_hwc).permute(0, 3, 1, 2).to(torch.float32).div(255)
+    m = torch.tensor(mean, dtype=torch.float32).view(1, 3, 1, 1)
+    s = torch.tensor(std, dtype=torch.float32).view(1, 3, 1, 1)
+    return x.sub(m).div(s)
+
+
 def downscale(imgs: torch.Tensor, scale: float) -> torch.Tensor:
     H, W = imgs.shape[-2:]
     return F.interpolate(imgs, [int(H * scale), int(W * scale)], mode="bilinear", align_corners=True)

@@ -259,3 +259,24 @@ def test_gop_runner_single_gpu(dev, manifest):
     assert out.shape == (11, 12, 48, 64)
     for d in range(1, 12):
         assert maxdiff(out[d - 1:d], single[(0, d)]) <= 2e-4
+
+
+def test_eval_alter_res_keyframe_cache(dev, manifest):
+    """EvalAlterRes(cache_keyframe=True): same mIoU as the reference-faithful evaluator, one HR forward per GOP."""
+    from arseg_amd import evaluation as ev, synth
+
+    hr, lr = _psp(manifest, dev, False), _psp(manifest, dev, True)
+    clip = synth.make_clip(3, 48, 64, gop=4)
+    key = torch.from_numpy(clip["frames"][0:1])
+    g = np.random.Generator(np.random.PCG64(9))
+    samples = []
+    for d in (1, 2, 3):
+        label = torch.from_numpy(g.integers(0, 12, (1, 48, 64)).astype(np.int64))
+        flow = torch.from_numpy(clip["mv"][d:d + 1].astype(np.float64) / 4)
+        samples.append((torch.from_numpy(clip["frames"][d:d + 1]), label, None, key.clone(), flow))
+    with torch.no_grad():
+        plain, cached = ev.EvalAlterRes(scale=0.5), ev.EvalAlterRes(scale=0.5, cache_keyframe=True)
+        m0 = plain(hr, lr, samples, 12)
+        m1 = cached(hr, lr, samples, 12)
+    assert m0 == m1
+    assert plain.hr_forwards == 3 and cached.hr_forwards == 1

@@ -476,3 +476,21 @@ def test_conv2d_f16x3_accuracy(dev):
         err[m] = float((got - want).abs().max() / want.abs().max())
     assert err["f32"] < 5e-6, err
     assert err["f16x3"] < 5e-6 and err["f16x3"] < 2 * err["f32"], err      # measured 1.5e-6 vs 2.3e-6; plain fp16 would be ~1e-3
+
+
+@pytest.mark.parametrize("H,W,h,w", [(36, 48, 18, 24), (35, 47, 17, 23), (20, 30, 20, 30)])
+def test_frame_u8_ingest(dev, H, W, h, w):
+    """uint8 HWC -> normalised NHWC4 in one kernel == ToTensor + Normalize + F.interpolate(align_corners=True) of the oracle,
+    and == the two-step GPU path (float frame -> frame_to_nhwc4)."""
+    from arseg_amd import ingest, ops
+    from oracle import cpu_ref
+
+    g = np.random.Generator(np.random.PCG64(61))
+    img = g.integers(0, 256, (2, H, W, 3), dtype=np.uint8)
+    got = ingest.frames_to_nhwc4(img, h, w, ingest.CITY_BISE_MEAN, ingest.CITY_BISE_STD, device=dev)
+    norm = cpu_ref.to_tensor_normalize(img, ingest.CITY_BISE_MEAN, ingest.CITY_BISE_STD)
+    want = F.interpolate(norm, (h, w), mode="bilinear", align_corners=True) if (h, w) != (H, W) else norm
+    assert got.shape == (2, h, w, 4) and float(got[..., 3].abs().max()) == 0.0
+    assert maxdiff(got[..., :3].permute(0, 3, 1, 2), want) <= 1e-5      # fp32 lerp of values up to +-4 (FMA contraction on the GPU)
+    two_step = ops.frame_to_nhwc4(norm.to(dev), h, w)
+    assert maxdiff(got, two_step) <= 1e-5
