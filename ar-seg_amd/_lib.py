@@ -67,6 +67,8 @@ PROTOTYPES = {
     "arseg_head_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_frame_to_nhwc4_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_frame_u8_to_nhwc4_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), _STREAM]),
+    "arseg_merge_motion_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "arseg_merge_motion_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_nchw_to_nhwc_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_nhwc_to_nchw_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _STREAM]),
     "arseg_argmax_confusion_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_STREAM]),

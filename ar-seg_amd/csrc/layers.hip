@@ -286,6 +286,40 @@ __global__ __launch_bounds__(256) void frame_u8_to_nhwc4_kernel(const uint8_t *_
     }
 }
 
+// ------------------------------------------------------------------ mergeMotion: chain per-frame codec MVs to the keyframe
+// (pre-process/generate_compressed_dataset_camvid.py:6-56).  Frames are sequential (a pixel links to the parent of its
+// target in an earlier frame), pixels independent: one launch per frame, an integer gather from the earlier frames' links.
+// dp[f][y][x] = int4 (x, y, frame, -) of the linked position, frame == -1: no link yet (the keyframe).
+__device__ __forceinline__ int round_half_even_div4(int v) {        // np.round(v / 4) for integer v
+    const int b = v >> 2, r = v & 3;                                  // v = 4b + r, floor division
+    return r < 2 ? b : (r > 2 ? b + 1 : b + (b & 1));                 // .5 -> the even neighbour
+}
+__global__ __launch_bounds__(256) void merge_motion_step_kernel(const int16_t *__restrict__ flow, int4 *__restrict__ dp, int f1, int H, int W) {
+    const int hw = H * W;
+    for (int pix = blockIdx.x * blockDim.x + threadIdx.x; pix < hw; pix += gridDim.x * blockDim.x) {
+        const int y = pix / W, x = pix - y * W;
+        int mx = flow[(size_t)pix * 3], my = flow[(size_t)pix * 3 + 1], ref = flow[(size_t)pix * 3 + 2];
+        if (ref < 0 || ref >= 3) { mx = 0; my = 0; ref = 0; }           // intra block: zero motion, previous frame (:20-22)
+        const int j2 = min(max(y + round_half_even_div4(my), 0), H - 1), k2 = min(max(x + round_half_even_div4(mx), 0), W - 1);
+        const int f2 = max(0, f1 - ref - 1);
+        const int4 parent = dp[(size_t)f2 * hw + (size_t)j2 * W + k2];
+        dp[(size_t)f1 * hw + pix] = parent.z != -1 ? parent : make_int4(k2, j2, f2, 0);
+    }
+}
+__global__ __launch_bounds__(256) void merge_motion_out_kernel(const int4 *__restrict__ dp, int16_t *__restrict__ out, int F1, int H, int W) {
+    const long long total = (long long)F1 * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int pix = (int)(i % ((long long)H * W)), f = (int)(i / ((long long)H * W)), y = pix / W, x = pix - y * W;
+        const int4 d = dp[i];
+        // frame 0 keeps the initial -1 (the reference converts frames 1.. only, :53-54); astype(np.short) wraps like the cast
+        out[i * 2] = (int16_t)(f == 0 ? d.x : (d.x - x) * 4);
+        out[i * 2 + 1] = (int16_t)(f == 0 ? d.y : (d.y - y) * 4);
+    }
+}
+__global__ __launch_bounds__(256) void fill_int4_kernel(int4 *__restrict__ p, long long n, int v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = make_int4(v, v, v, v);
+}
+
 // ------------------------------------------------------------------ layout changes (LDS-tiled 32x32 transposes)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int HW,
                                                            int out_ld) {
@@ -465,6 +499,26 @@ extern "C" int arseg_frame_u8_to_nhwc4_fwd(const uint8_t *img_hwc, float *out, i
     if (std3[0] == 0.f || std3[1] == 0.f || std3[2] == 0.f) return ARSEG_EINVAL;
     hipLaunchKernelGGL(frame_u8_to_nhwc4_kernel, dim3(grid_for((long long)N * h * w)), dim3(256), 0, arseg_stream(stream), img_hwc, out, N, H,
                        W, h, w, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    return arseg_launch_status();
+}
+
+extern "C" size_t arseg_merge_motion_workspace_bytes(int n_frames, int H, int W) {
+    return n_frames < 0 || H <= 0 || W <= 0 ? 0 : (size_t)(n_frames + 1) * H * W * sizeof(int4);
+}
+
+extern "C" int arseg_merge_motion_fwd(const int16_t *flows, int16_t *out, void *workspace, size_t workspace_bytes, int n_frames, int frame_start,
+                                      int H, int W, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(flows); ARSEG_CHECK_PTR(out); ARSEG_CHECK_PTR(workspace); ARSEG_CHECK_POS(n_frames); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
+    if (frame_start < 0 || frame_start >= n_frames) return ARSEG_EINVAL;
+    if (workspace_bytes < arseg_merge_motion_workspace_bytes(n_frames, H, W)) return ARSEG_EWORKSPACE;
+    if (!ARSEG_ALIGNED16(workspace) || (long long)H * W > (1ll << 30)) return ARSEG_EINVAL;
+    hipStream_t st = arseg_stream(stream);
+    int4 *dp = reinterpret_cast<int4 *>(workspace);
+    const long long n = (long long)(n_frames + 1) * H * W;
+    hipLaunchKernelGGL(fill_int4_kernel, dim3(grid_for(n)), dim3(256), 0, st, dp, n, -1);
+    for (int f1 = frame_start + 1; f1 <= n_frames; ++f1)
+        hipLaunchKernelGGL(merge_motion_step_kernel, dim3(grid_for((long long)H * W)), dim3(256), 0, st, flows + (size_t)f1 * H * W * 3, dp, f1, H, W);
+    hipLaunchKernelGGL(merge_motion_out_kernel, dim3(grid_for(n)), dim3(256), 0, st, dp, out, n_frames + 1, H, W);
     return arseg_launch_status();
 }
 

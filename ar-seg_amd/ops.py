@@ -619,6 +619,21 @@ def frame_u8_to_nhwc4(img_u8: torch.Tensor, h: int, w: int, mean, std) -> torch.
     return out
 
 
+def merge_motion(flows: torch.Tensor, frame_start: int = 0) -> torch.Tensor:
+    """Codec motion fields int16 [F+1,H,W,3] (mv_x, mv_y quarter-pel, reference index; on the GPU) -> accumulated quarter-pel
+    motion to the keyframe, int16 [F+1,H,W,2] (frame 0 = -1, as the reference's mergeMotion leaves it)."""
+    if flows.dtype != torch.int16 or not flows.is_cuda or flows.dim() != 4 or flows.shape[-1] != 3:
+        raise _lib.ArsegError("merge_motion expects a CUDA int16 tensor [F+1,H,W,3]")
+    flows = flows.contiguous()
+    F1, H, W, _ = flows.shape
+    lib = _lib.load()
+    nbytes = lib.arseg_merge_motion_workspace_bytes(F1 - 1, H, W)
+    ws = workspace(nbytes, flows.device)
+    out = torch.empty((F1, H, W, 2), dtype=torch.int16, device=flows.device)
+    _launch("merge_motion", lib.arseg_merge_motion_fwd, _ptr(flows), _ptr(out), _ptr(ws), nbytes, F1 - 1, frame_start, H, W, _stream())
+    return out
+
+
 def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int, W: int, hist: Optional[torch.Tensor] = None,
                      ignore_label: int = 255, want_pred: bool = True):
     """Evaluator tail (evaluation.py:201-209): returns (pred int32 [N,H,W] or None, hist int64 [n_cls,n_cls] or None)."""

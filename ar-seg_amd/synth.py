@@ -176,3 +176,19 @@ def resolve_aliases(sd):
                 if ck in out:
                     out[ck] = sd[k]
     return out
+
+
+def make_mv_chain(seed: int, H: int, W: int, n_frames: int) -> np.ndarray:
+    """Per-frame codec motion fields as mergeMotion reads them (pre-process/generate_compressed_dataset_camvid.py:16-17):
+    int16 [n_frames+1, H, W, 3] = (mv_x, mv_y in quarter-pel, reference index), entry 0 unused.  Block-constant on 8/16-px
+    blocks, odd quarter-pel values (rounding, incl. exact halves), reference indices 0..2 plus intra markers (-1, 5)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    out = np.zeros((n_frames + 1, H, W, 3), dtype=np.int16)
+    for f in range(1, n_frames + 1):
+        bs = 8 if f % 2 else 16
+        hb, wb = (H + bs - 1) // bs, (W + bs - 1) // bs
+        mv = g.integers(-70, 71, (hb, wb, 2))                      # quarter-pel, ~ +-17 px, all residues mod 4
+        ref = g.choice(np.array([0, 0, 0, 1, 2, -1, 5]), (hb, wb))
+        blk = np.concatenate([mv, ref[..., None]], axis=-1).astype(np.int16)
+        out[f] = np.repeat(np.repeat(blk, bs, axis=0), bs, axis=1)[:H, :W]
+    return out

@@ -214,6 +214,14 @@ int arseg_frame_to_nhwc4_fwd(const float *img, float *out, int N, int H, int W, 
  * (evaluation.py:186-188) in one pass.  mean3 / std3: host pointers to 3 floats. */
 int arseg_frame_u8_to_nhwc4_fwd(const uint8_t *img_hwc, float *out, int N, int H, int W, int h, int w, const float *mean3,
                                 const float *std3, arseg_stream_t stream);
+
+/* mergeMotion (pre-process/generate_compressed_dataset_camvid.py:6-56): chains the codec's per-frame motion fields back to
+ * the keyframe.  flows: int16 [n_frames+1][H][W][3] = (mv_x, mv_y quarter-pel, reference index), entries <= frame_start unused;
+ * out: int16 [n_frames+1][H][W][2], frame f > 0 = accumulated quarter-pel motion of frame f to the keyframe (what the
+ * datasets' .bin files hold), frame 0 = -1 as in the reference.  workspace: arseg_merge_motion_workspace_bytes() bytes. */
+size_t arseg_merge_motion_workspace_bytes(int n_frames, int H, int W);
+int arseg_merge_motion_fwd(const int16_t *flows, int16_t *out, void *workspace, size_t workspace_bytes, int n_frames, int frame_start,
+                           int H, int W, arseg_stream_t stream);
 /* layout changes at the API boundary */
 int arseg_nchw_to_nhwc_fwd(const float *in, float *out, int N, int C, int HW, int out_ld, arseg_stream_t stream);
 int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);

@@ -29,6 +29,7 @@ from __future__ import annotations
 
 from typing import Dict, Tuple
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -455,3 +456,34 @@ def alter_res_step(kind: str, sd_hr: SD, sd_lr: SD, img: torch.Tensor, ref_img: 
         out_p = bisenet_fuse_phase1(sd_lr, lr)[-1]
         out, p = bisenet_fuse_phase2(sd_lr, out_p, warped)
     return out, p, warped, ref_p
+
+
+# ----------------------------------------------------------------------------------------------
+# f4  mergeMotion: chain per-frame codec MVs back to the keyframe
+#                                        pre-process/generate_compressed_dataset_camvid.py:6-56
+# ----------------------------------------------------------------------------------------------
+def merge_motion(flows, frame_start: int = 0):
+    """flows: int16 [F+1,H,W,3] (mv_x, mv_y quarter-pel, reference index; entry <= frame_start unused).
+    Returns int32 [H,W,F+1,2]: for frames > frame_start the accumulated quarter-pel motion to the keyframe, -1 for frame
+    `frame_start` and earlier (the reference never overwrites them).  Restated step by step: intra blocks (ref < 0 or >= 3)
+    get zero motion and reference 0 (:20-22); target = pixel + np.round(mv/4) (half to even, :26-27), clipped into the image
+    (:33-34); target frame f2 = max(0, f1 - ref - 1) (:28); if the target already has a parent the pixel links to the
+    target's parent, otherwise to the target itself (:37-49; the `== 90` branch is dead after the intra masking); finally
+    (x, y) positions become quarter-pel displacements (:53-54)."""
+    flows = np.array(flows, dtype=np.int16, copy=True)
+    F1, H, W, _ = flows.shape
+    dp = np.full((H, W, F1, 3), -1, dtype=np.int32)
+    k1, j1 = np.meshgrid(np.arange(W), np.arange(H))
+    for f1 in range(frame_start + 1, F1):
+        flow = flows[f1]
+        intra = np.logical_or(flow[..., 2] < 0, flow[..., 2] >= 3)
+        flow[intra] = 0
+        j2 = np.clip(j1 + np.round(flow[..., 1] / 4).astype(int), 0, H - 1)
+        k2 = np.clip(k1 + np.round(flow[..., 0] / 4).astype(int), 0, W - 1)
+        f2 = np.maximum(0, f1 - flow[..., 2].astype(int) - 1)
+        parent = dp[j2, k2, f2]                                                 # [H,W,3]
+        has_parent = parent[..., 2] != -1
+        dp[:, :, f1] = np.where(has_parent[..., None], parent, np.stack([k2, j2, f2], axis=-1))
+    dp[:, :, 1:, 0] = (dp[:, :, 1:, 0] - k1[..., None]) * 4
+    dp[:, :, 1:, 1] = (dp[:, :, 1:, 1] - j1[..., None]) * 4
+    return dp[:, :, :, :2]

@@ -142,8 +142,38 @@ def gen_g8(manifest):
              merge_equal=np.array([torch.equal(outm, out2), torch.equal(pm, p2)]), out_plain=outp)
 
 
+def gen_g9(manifest):
+    """G9: mergeMotion (pre-process/generate_compressed_dataset_camvid.py:6-56).  The script
+    around the function encodes videos at import time, so only the function's own lines are executed, with cv2.imread
+    (absent here; used for the frame size only) replaced and the 720x960 .bin files it reads written to a scratch directory."""
+    import hashlib
+    import tempfile
+
+    path = os.path.join(REF, "pre-process", "generate_compressed_dataset_camvid.py")
+    lines = open(path).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("def mergeMotion("))
+    end = next(i for i in range(start + 1, len(lines)) if lines[i] and not lines[i][0].isspace())
+    cv2_stub = types.SimpleNamespace(imread=lambda p: np.zeros((720, 960, 3), np.uint8))
+    ns = {"os": os, "np": np, "cv2": cv2_stub, "print": lambda *a, **k: None}
+    exec(compile("\n".join(lines[start:end]), path, "exec"), ns)
+    print("G9 mergeMotion")
+    F = 4
+    flows = synth.make_mv_chain(11, 720, 960, F)
+    with tempfile.TemporaryDirectory() as d:
+        for f in range(1, F + 1):
+            flows[f].tofile(os.path.join(d, "test_%03d.bin" % f))
+        out = ns["mergeMotion"](d, 0, F)                                   # int32 [720,960,F+1,2]
+    save("g9_mergemotion", seed=11, F=F, out_s=out[::9, ::8].astype(np.int32), frame_last_crop=out[100:164, 200:296, F].astype(np.int32),
+         sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8))
+
+
 def main():
     install_shims()
+    if "--only-g9" in sys.argv:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_g9(manifest)
+        return
     if "--only-g8" in sys.argv:                 # added after the first batch: leaves the other vectors untouched
         with open(os.path.join(HERE, "manifest.json")) as f:
             manifest = json.load(f)
@@ -294,6 +324,7 @@ def main():
             manifest[f"g7_{kind}_miou_const"] = float(miou_c)
 
     gen_g8(manifest)
+    gen_g9(manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("done")

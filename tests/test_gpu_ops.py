@@ -494,3 +494,16 @@ def test_frame_u8_ingest(dev, H, W, h, w):
     assert maxdiff(got[..., :3].permute(0, 3, 1, 2), want) <= 1e-5      # fp32 lerp of values up to +-4 (FMA contraction on the GPU)
     two_step = ops.frame_to_nhwc4(norm.to(dev), h, w)
     assert maxdiff(got, two_step) <= 1e-5
+
+
+@pytest.mark.parametrize("H,W,F_", [(720, 960, 4), (37, 53, 11), (8, 8, 1)])
+def test_merge_motion(dev, H, W, F_):
+    """GPU mergeMotion == the oracle (itself pinned to the reference's function, G9), bit for bit, as the int16 arrays the
+    dataset's .bin files hold (astype(np.short) of the oracle's int32)."""
+    from arseg_amd import ops, synth
+    from oracle import cpu_ref
+
+    flows = synth.make_mv_chain(21 + F_, H, W, F_)
+    want = cpu_ref.merge_motion(flows).transpose(2, 0, 1, 3).astype(np.int16)           # [F+1,H,W,2]
+    got = ops.merge_motion(torch.from_numpy(flows).to(dev)).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)

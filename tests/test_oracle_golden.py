@@ -148,3 +148,19 @@ def test_g7_alter_res_step(golden, manifest, kind, hr_name, hr_seed, lr_name, lr
     assert (preds.numpy() != g["preds"]).mean() <= 1e-3          # argmax ties at 1e-5 noise only
     assert abs(float(cpu_ref.miou(t(g["hist"]))) - float(g["miou"])) <= 1e-6
     assert float((hist - t(g["hist"])).abs().sum()) <= 4
+
+
+def test_g9_merge_motion(golden):
+    """mergeMotion restatement vs the reference function's own output on the same seeded 720x960 motion fields (G9):
+    strided sample, a dense crop of the last frame and the SHA-256 of the full int32 array."""
+    import hashlib
+
+    from arseg_amd import synth
+
+    g = golden("g9_mergemotion")
+    F_ = int(g["F"])
+    flows = synth.make_mv_chain(int(g["seed"]), 720, 960, F_)
+    out = cpu_ref.merge_motion(flows)
+    assert out.shape == (720, 960, F_ + 1, 2) and out.dtype == np.int32
+    assert np.array_equal(out[::9, ::8], g["out_s"]) and np.array_equal(out[100:164, 200:296, F_], g["frame_last_crop"])
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest() == g["sha256"].tobytes()
