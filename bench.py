@@ -46,6 +46,8 @@ CONFIGS = {
                   label="PSPNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @1024x2048"),
     "semseg": dict(kind="semseg", H=1024, W=2048, n_cls=19, C=512, feat_div=8, ref_lr_gflop=0.0, ref_hr_gflop=0.0,
                    label="Cityscapes PSPNet-18 (model/pspnet_semseg.py) HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 C=512 @128x256"),
+    "bise03": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=0.0, ref_hr_gflop=242.8, scale=0.3,
+                   label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.3x (307x614) + CReFF 7x7 @128x256 (BASELINE configs[4] shapes, fp32 tensors)"),
     "bise": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=60.6, ref_hr_gflop=242.8,
                  label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256"),
 }
@@ -105,6 +107,8 @@ def main():
     _lib.load()
     ops.set_conv_math(args.conv_math)
     cfg = CONFIGS[args.config]
+    global SCALE
+    SCALE = cfg.get("scale", SCALE)
     H, W, N_CLS = cfg["H"], cfg["W"], cfg["n_cls"]
     mean, std = (synth.CAMVID_MEAN, synth.CAMVID_STD) if cfg["kind"] == "psp" else (synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)
     hr, lr, sd_hr, sd_lr = build_nets(dev, cfg)
@@ -170,6 +174,7 @@ def main():
         "metric": {"psp": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
                    "psp2k": "non-keyframe frames/sec (backbone+CReFF), PSPNet-18 1024x2048 / LR 512x1024",
                    "semseg": "non-keyframe frames/sec (backbone+CReFF), Cityscapes PSPNet-18 1024x2048 / LR 512x1024",
+                   "bise03": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614",
                    "bise": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024"}[args.config],
         "value": nonkey_per_step * args.steps / elapsed,
         "unit": "frames/s",
