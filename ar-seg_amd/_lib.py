@@ -18,7 +18,7 @@ NCHW, NHWC, C8 = 0, 1, 2
 FLOW_F32, FLOW_F64 = 0, 1
 NEAREST, BILINEAR = 0, 1
 REDUCE_MEAN, REDUCE_MAX = 0, 1
-MATH_F32, MATH_F16X3 = 0, 1
+MATH_F32, MATH_F16X3, MATH_F16 = 0, 1, 2
 
 
 class ConvDesc(Structure):

@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 split_f16x3(__builtin_bit_cast(f32x4, rg.a[i]), hi, lo);
                 *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + (chunk & 7) * 2) = hi;
                 *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + 16 + (chunk & 7) * 2) = lo;
+            } else if (MATH == ARSEG_MATH_F16) {        // plain fp16 operands (round to nearest), the lo halves stay unused
+                const f32x4 v = __builtin_bit_cast(f32x4, rg.a[i]);
+                typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+                const h16x4 hv = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<h16x4 *>(row + (chunk >> 3) * 32 + (chunk & 7) * 2) = hv;
             } else {
                 *reinterpret_cast<u32x4 *>(row + chunk * 4) = rg.a[i];
             }
@@ -207,7 +212,23 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int r = 0; r < 16; ++r) acc2[0][r] = 0.0f;
 
     auto compute = [&](int cur) {
-        if (MATH == ARSEG_MATH_F16X3) {
+        if (MATH == ARSEG_MATH_F16) {                  // one fp16 MFMA per product: the hi halves only
+            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
+            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int ko = (ks >> 1) * 32 + (ks & 1) * 8;
+                h16x8 fa[TM], fb[TN];
+#pragma unroll
+                for (int t = 0; t < TM; ++t) fa[t] = *reinterpret_cast<const h16x8 *>(ah + t * 32 * LDS_LD + ko);
+#pragma unroll
+                for (int t = 0; t < TN; ++t) fb[t] = *reinterpret_cast<const h16x8 *>(bh + t * 32 * LDS_LD + ko);
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                    for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[tm], fb[tn], acc[tm][tn], 0, 0, 0);
+            }
+        } else if (MATH == ARSEG_MATH_F16X3) {
             // lane (li, lh) holds k = 16*ks + 8*lh + 0..7 of row li: one ds_read_b128 per operand and precision half
             const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
             const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
@@ -544,7 +565,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
         return ARSEG_EINVAL;
     if ((d->Cin & 3) || (d->in_ld & 3) || d->in_ld < d->Cin || d->out_ld < d->Cout) return ARSEG_EINVAL;
     if (d->R * d->S > 1 && (d->Cin & (d->Cin - 1))) return ARSEG_EUNSUPPORTED;
-    if (d->math != ARSEG_MATH_F32 && d->math != ARSEG_MATH_F16X3) return ARSEG_EINVAL;
+    if (d->math != ARSEG_MATH_F32 && d->math != ARSEG_MATH_F16X3 && d->math != ARSEG_MATH_F16) return ARSEG_EINVAL;
     pl->Ho = (d->H + 2 * d->pad - d->dil * (d->R - 1) - 1) / d->stride + 1;
     pl->Wo = (d->W + 2 * d->pad - d->dil * (d->S - 1) - 1) / d->stride + 1;
     if (pl->Ho <= 0 || pl->Wo <= 0) return ARSEG_EINVAL;
@@ -727,7 +748,8 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
         if (pl.bm == 256) return pl.bn == 64 ? launch_patch<64, 4>(p, pl, d->dil, hs) : launch_patch<128, 4>(p, pl, d->dil, hs);
         return pl.bn == 64 ? launch_patch<64, 2>(p, pl, d->dil, hs) : launch_patch<128, 2>(p, pl, d->dil, hs);
     }
-    st = d->math == ARSEG_MATH_F16X3 ? launch_math<ARSEG_MATH_F16X3>(p, pl, hs) : launch_math<ARSEG_MATH_F32>(p, pl, hs);
+    st = d->math == ARSEG_MATH_F16X3 ? launch_math<ARSEG_MATH_F16X3>(p, pl, hs)
+         : (d->math == ARSEG_MATH_F16 ? launch_math<ARSEG_MATH_F16>(p, pl, hs) : launch_math<ARSEG_MATH_F32>(p, pl, hs));
     if (st != ARSEG_OK) return st;
     if (pl.nsplit > 1) {
         const long long total = (long long)pl.M * (d->Cout >> 2);

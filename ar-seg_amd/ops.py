@@ -292,12 +292,12 @@ def _nhwc_ld(t: torch.Tensor) -> int:
 _AUTOTUNE = os.environ.get("ARSEG_CONV_AUTOTUNE", "1") != "0"
 # Which MFMA back end evaluates the fp32 GEMMs (include/arseg_hip.h: enum arseg_math): "f16x3" = fp32 emulated with three
 # fp16 MFMAs on hi/lo-split operands (22-bit significands, fp32 accumulate), "f32" = the fp32 MFMA.
-_MATH_NAMES = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3}
+_MATH_NAMES = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16}      # "f16": reduced precision (plain fp16 operands)
 _math = _MATH_NAMES[os.environ.get("ARSEG_CONV_MATH", "f16x3")]
 
 
 def set_conv_math(name: str) -> str:
-    """Select the conv arithmetic back end ("f32" | "f16x3") for subsequent launches; returns the previous one."""
+    """Select the conv arithmetic back end ("f32" | "f16x3" | "f16") for subsequent launches; returns the previous one."""
     global _math
     prev = [k for k, v in _MATH_NAMES.items() if v == _math][0]
     _math = _MATH_NAMES[name]
@@ -372,7 +372,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     d.act, d.prelu_slope = pc.act, pc.slope
     d.tile_cfg, d.split_k = tile_cfg, split_k
     d.math = math = _math
-    w_dev, scale_dev = (pc.w_h3, pc.scale_h3) if math == _lib.MATH_F16X3 else (pc.w, pc.scale)
+    w_dev, scale_dev = (pc.w_h3, pc.scale_h3) if math != _lib.MATH_F32 else (pc.w, pc.scale)
     d.out_ld, d.res_ld = pc.cout, pc.cout     # provisional, for the shape query
     lib = _lib.load()
     ho, wo = ctypes.c_int(), ctypes.c_int()
@@ -455,7 +455,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     d.act, d.prelu_slope = _lib.ACT_NONE, 0.0
     d.batch, d.in_batch_stride, d.w_batch_stride, d.out_batch_stride = 36, T * Cin, Cout * Cin, T * Cout
     d.math = math = _math
-    u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math == _lib.MATH_F16X3 else (pc.wino_u, pc.scale)
+    u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math != _lib.MATH_F32 else (pc.wino_u, pc.scale)
     key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
     plan = _conv_plans.get(key)
 

@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
-    ap.add_argument("--conv-math", choices=["f16x3", "f32"], default="f16x3",
+    ap.add_argument("--conv-math", choices=["f16x3", "f32", "f16"], default="f16x3",
                     help="MFMA back end of the fp32 conv GEMMs: f16x3 = split-fp16 emulation (3 fp16 MFMAs, fp32 accumulate), f32 = fp32 MFMA")
     args = ap.parse_args()
 
@@ -181,8 +181,9 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "conv_math": args.conv_math + (" (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)" if args.conv_math == "f16x3" else " (fp32 MFMA)"),
+        "dtype": "f16" if args.conv_math == "f16" else "f32", "data": "synthetic",
+        "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
+                                       "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
         "streams": len(streams),
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32 tensors",
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
@@ -215,7 +216,7 @@ def main():
             sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9          # 2*MACs of every conv/linear of the reference (hook-counted)
         # f16x3: every GEMM MAC is three fp16 MFMA MACs -> executed matrix-core FLOPs = 3 x the GEMM FLOPs, against the fp16 peak
-        mfma_mult, peak = (3.0, PEAK_F16_MFMA_TFLOPS) if args.conv_math == "f16x3" else (1.0, PEAK_FP32_MFMA_TFLOPS)
+        mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]
         gemm_tf = tot_flops / (tot_ms * 1e-3) / 1e12
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
@@ -224,7 +225,8 @@ def main():
                 traffic = json.load(f).get(args.conv_math, {}).get("hbm_bytes_per_launch")
         result["roofline"] = {
             "kernel": "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> (implicit GEMM / batched Winograd GEMM; " +
-                      ("3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)" if args.conv_math == "f16x3" else "v_mfma_f32_32x32x2_f32)"),
+                      {"f16x3": "3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)", "f16": "v_mfma_f32_32x32x16_f16 on fp16-rounded operands)",
+                       "f32": "v_mfma_f32_32x32x2_f32)"}[args.conv_math],
             "bound": "mfma", "achieved": mfma_mult * gemm_tf, "peak": peak, "unit": "TFLOP/s",
             "frac": mfma_mult * gemm_tf / peak,
             "traffic": traffic,

@@ -136,8 +136,10 @@ typedef struct arseg_conv_desc {
  * ARSEG_MATH_F16X3: fp32 emulated on the fp16 matrix cores: x = hi + lo (two fp16, 22 significant bits),
  *                   a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi with fp32 accumulation (error ~2^-21 relative per product,
  *                   operands must satisfy |x| < 65504).  w_packed from arseg_split_weight_f16x3_host, and `scale` must
- *                   carry that function's per-channel chan_mul_inv factor. */
-enum arseg_math { ARSEG_MATH_F32 = 0, ARSEG_MATH_F16X3 = 1 };
+ *                   carry that function's per-channel chan_mul_inv factor.
+ * ARSEG_MATH_F16:   reduced precision: plain fp16 operands (activations rounded to nearest, the hi halves of the same split
+ *                   weights), one fp16 MFMA per product, fp32 accumulation; ~1e-3 relative error per conv.  Not used by default. */
+enum arseg_math { ARSEG_MATH_F32 = 0, ARSEG_MATH_F16X3 = 1, ARSEG_MATH_F16 = 2 };
 
 int arseg_conv_out_hw(const arseg_conv_desc *d, int *Ho, int *Wo);
 size_t arseg_conv2d_workspace_bytes(const arseg_conv_desc *d);

@@ -507,3 +507,28 @@ def test_merge_motion(dev, H, W, F_):
     want = cpu_ref.merge_motion(flows).transpose(2, 0, 1, 3).astype(np.int16)           # [F+1,H,W,2]
     got = ops.merge_motion(torch.from_numpy(flows).to(dev)).cpu().numpy()
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_conv2d_f16_reduced_precision(dev):
+    """ARSEG_MATH_F16 (plain fp16 operands, fp32 accumulate): works on every tile shape and is, as documented, a reduced
+    precision mode -- ~1e-3 relative, three orders of magnitude above the split-fp16 default."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    x = rnd(95, 2, 128, 20, 24)
+    w = rnd(96, 96, 128, 3, 3, scale=0.03)
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    prev = ops.set_conv_math("f16")
+    try:
+        errs = []
+        for cfg in (5, 6, 7, 8, 9, 11, 1):
+            got = ops.conv2d(xd, pc, tile_cfg=cfg, split_k=1).permute(0, 3, 1, 2).cpu().double()
+            errs.append(float((got - want).abs().max() / want.abs().max()))
+        got_w = torch.empty((2, 20, 24, 96), device=dev)
+        ops._conv_wino(xd, pc, None, got_w, 2, 20, 24)
+        errs.append(float((got_w.permute(0, 3, 1, 2).cpu().double() - want).abs().max() / want.abs().max()))
+    finally:
+        ops.set_conv_math(prev)
+    assert max(errs[:-1]) < 2e-3 and min(errs) > 2e-5 and errs[-1] < 2e-2, errs      # direct ~5e-4; Winograd amplifies it to ~9e-3
