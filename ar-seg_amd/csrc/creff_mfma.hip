@@ -20,6 +20,7 @@
 // image = the unfold's padding, model/attention.py:56-58), the query convolution is lane-local (each lane convolves the
 // 4 channels of its own query that its B operand needs).
 #include "creff_params.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,14 +30,20 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x6 __attribute__((ext_vector_type(6)));
 
-constexpr int TX = 16, TY = 16, NT = 1024;
+constexpr int TX = 16;
 constexpr int G = 4;                                  // float4 groups per 16-channel chunk
-constexpr int RH = 22, RW = 24, RWC = 22;             // key/value region: rows, record columns, computed columns
-constexpr int KPLK = RH * RW, KPLV = RH * RW + 4;     // plane stride of the key / value records: keys are read with ds_read_b128
-                                                      // (planes on the same banks), values with the transpose read (planes 16 banks apart)
-constexpr int HH = 24, HWD = 26, HPL = HH * HWD;      // staged hr chunk (+3 window halo +1 conv halo), one plane per group
-constexpr int LH = 18, LWD = 18, LPL = LH * LWD + 4;  // upsampled lr tile (+1 conv halo)
+constexpr int RW = 24, RWC = 22;                      // key/value region: record columns, computed columns
+constexpr int HWD = 26, LWD = 18;                     // columns of the staged hr chunk (+3 window +1 conv halo) / of the lr_up tile
 constexpr int LWCAP = 512;                            // raw lr window capacity (float4): 128 low-resolution pixels
+// Tile height TY (16: one 16-wave workgroup per CU with double-buffered hr staging; 8: 8 waves, single-buffered hr staging,
+// half the LDS so that two workgroups share a CU and cover each other's barriers and DMA latency).
+template <int TY> struct Geo {
+    static constexpr int NT = 64 * TY, HBUF = TY == 16 ? 2 : 1;
+    static constexpr int RH = TY + 6, HH = TY + 8, LH = TY + 2;
+    static constexpr int KPLK = RH * RW, KPLV = RH * RW + 4;   // plane stride of the key / value records: keys are read with ds_read_b128
+                                                               // (planes on the same banks), values with the transpose read (16 banks apart)
+    static constexpr int HPL = HH * HWD, LPL = LH * LWD + 4;
+};
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
 
@@ -91,12 +98,14 @@ __device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigne
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
-template <int NB>      // classifier row blocks of 16 classes (0: no head)
-__global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
+template <int NB, int TY>      // NB: classifier row blocks of 16 classes (0: no head)
+__global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParams p) {
     constexpr int NBA = NB > 0 ? NB : 1;
+    typedef Geo<TY> GE;
+    constexpr int NT = GE::NT, HBUF = GE::HBUF, RH = GE::RH, HH = GE::HH, LH = GE::LH, KPLK = GE::KPLK, KPLV = GE::KPLV, HPL = GE::HPL, LPL = GE::LPL;
     extern __shared__ __attribute__((aligned(16))) f32x4 smem4[];
     f32x4 *Hs = smem4;                          // [2][G][HPL]   (double buffered, filled by LDS-DMA)
-    f32x4 *Ls = Hs + 2 * G * HPL;               // [G][LPL]
+    f32x4 *Ls = Hs + HBUF * G * HPL;            // [G][LPL]
     f32x4 *Lw = Ls + G * LPL;                   // [2] raw lr window [G][px]
     f32x4 *Wd = Lw + 2 * LWCAP;                 // [2][3 convs][9 taps + bias][G]
     f32x4 *Wfs = Wd + 2 * 3 * 10 * G;           // [2][G][NBA*16]: classifier slice of a chunk, {4 hi | 4 lo} halves per entry
@@ -195,11 +204,14 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int lw_tot = G * ly_n * lx_n;
     f32x4 pf_w;
-    auto issue = [&](int k, int buf, bool head) {
+    auto issue_hr = [&](int k, int buf) {
 #pragma unroll
         for (int it = 0; it < H_NI; ++it)
             if (it * NT + wave_u * 64 < H_TOT)
-                dma16_buf(h_rsrc, hoff[it] + k * h_chunk, lds_addr(Hs + buf * G * HPL + it * NT + wave_u * 64));
+                dma16_buf(h_rsrc, hoff[it] + k * h_chunk, lds_addr(Hs + (HBUF == 2 ? buf : 0) * G * HPL + it * NT + wave_u * 64));
+    };
+    auto issue = [&](int k, int buf, bool head) {
+        if (HBUF == 2) issue_hr(k, buf);           // double buffered: nobody reads the other half now
         if (wave_u * 64 < lw_tot) {
             const int i = min(tid, lw_tot - 1);          // surplus lanes of the last wave repeat the last item (stay inside Lw)
             const int npx = ly_n * lx_n, gg = i / npx, px = i - gg * npx, r = px / lx_n, c = px - r * lx_n;
@@ -230,7 +242,7 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
     };
     // key (cv=1) or value (cv=2) records of the region: bias + dw3x3(Hs), zero outside the image, split to fp16 hi/lo
     auto conv_kv = [&](int cv, int buf) {
-        const f32x4 *w = Wd + (buf * 3 + cv) * 10 * G, *hs = Hs + buf * G * HPL;
+        const f32x4 *w = Wd + (buf * 3 + cv) * 10 * G, *hs = Hs + (HBUF == 2 ? buf : 0) * G * HPL;
 #pragma unroll
         for (int it = 0; it < K_NI; ++it) {
             const f32x4 *h = hs + kh[it];
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
 
     // ------------------------------------------------------------------ pass 1: scores
     issue(0, 0, false);
+    if (HBUF == 1) issue_hr(0, 0);
     for (int k = 0; k < CB; ++k) {
         const int buf = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's share of chunk k has landed
@@ -282,6 +295,7 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
         }
         conv_kv(1, buf);
         __syncthreads();
+        if (HBUF == 1) issue_hr(k + 1 < CB ? k + 1 : 0, 0);      // single hr buffer: free now that the key records are built
         // query conv, lane local: channels 4g..4g+3 of this lane's own pixel
         const f32x4 *w = Wd + (buf * 3 + 0) * 10 * G;
         f32x4 qv = w[9 * G + g];
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
         conv_kv(2, buf);
         const f32x4 lrc = lr_up(Lw + buf * LWCAP, yq + 1, xq + 1, g);      // residual term, channels 4g..4g+3 (table rows clamp into the image)
         __syncthreads();
+        if (HBUF == 1 && k + 1 < CB) issue_hr(k + 1, 0);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -414,18 +429,20 @@ __global__ __launch_bounds__(NT) void creff_mfma_kernel(const CreffParams p) {
     }
 }
 
-template <int NB>
+template <int NB, int TY>
 int launch(const CreffParams &p, hipStream_t st) {
     constexpr int NBA = NB > 0 ? NB : 1;
-    const size_t smem = ((size_t)2 * G * HPL + (size_t)G * LPL + 2 * LWCAP + 2 * 3 * 10 * G + 2 * G * NBA * 16) * sizeof(f32x4) + (LH + LWD) * sizeof(f32x4) + (size_t)G * KPLV * sizeof(u32x4);
+    typedef Geo<TY> GE;
+    const size_t smem = ((size_t)GE::HBUF * G * GE::HPL + (size_t)G * GE::LPL + 2 * LWCAP + 2 * 3 * 10 * G + 2 * G * NBA * 16) * sizeof(f32x4) +
+                        (GE::LH + LWD) * sizeof(f32x4) + (size_t)G * GE::KPLV * sizeof(u32x4);
     static bool attr_set = false;     // idempotent; a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_mfma_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_mfma_kernel<NB, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(arseg_cdiv(p.Wp, TX), arseg_cdiv(p.Hp, TY), p.N);
-    hipLaunchKernelGGL((creff_mfma_kernel<NB>), grid, dim3(NT), smem, st, p);
+    hipLaunchKernelGGL((creff_mfma_kernel<NB, TY>), grid, dim3(GE::NT), smem, st, p);
     return arseg_launch_status();
 }
 
@@ -434,9 +451,17 @@ int launch(const CreffParams &p, hipStream_t st) {
 int arseg_creff_mfma_launch(const CreffParams &p, hipStream_t st) {
     if (p.C & 15) return ARSEG_EUNSUPPORTED;
     // the raw lr window under a tile (+1 halo, +1 for the second bilinear tap) must fit its LDS slot
-    const int wy = (int)((TY + 1) * p.sy) + 3, wx = (int)((TX + 1) * p.sx) + 3;
+    const int wy = (int)((16 + 1) * p.sy) + 3, wx = (int)((TX + 1) * p.sx) + 3;
     if (G * wy * wx > LWCAP) return ARSEG_EUNSUPPORTED;
     if (p.n_cls > 32) return ARSEG_EUNSUPPORTED;
-    if (p.n_cls == 0) return launch<0>(p, st);
-    return p.n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
+    // 16-row tiles (one 16-wave workgroup per CU) are faster per frame once the launch fills the chip (batched frames:
+    // 0.089 vs 0.104 ms per BiSeNet frame); small launches -- a single 128x256 map is 128 such tiles -- do better with
+    // 8-row tiles, twice the workgroups, two per CU (109 vs 151 us).  ARSEG_CREFF_TY=8|16 pins one (tests, measurements).
+    const char *e = getenv("ARSEG_CREFF_TY");
+    const int ty_env = e ? atoi(e) : 0;
+    const long long tiles16 = (long long)arseg_cdiv(p.Wp, TX) * arseg_cdiv(p.Hp, 16) * p.N;
+    const bool ty8 = ty_env == 8 || (ty_env != 16 && tiles16 < 512);
+    if (p.n_cls == 0) return ty8 ? launch<0, 8>(p, st) : launch<0, 16>(p, st);
+    if (p.n_cls <= 16) return ty8 ? launch<1, 8>(p, st) : launch<1, 16>(p, st);
+    return ty8 ? launch<2, 8>(p, st) : launch<2, 16>(p, st);
 }

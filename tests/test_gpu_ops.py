@@ -147,13 +147,15 @@ def test_creff_golden(dev, golden, ci, seed):
     (8, 18, 34, 9, 17, 3, 0, False),        # 3x3 window
     (32, 70, 40, 50, 80, 7, 32, False),     # lr larger than hr in one dim, 32 classes
 ])
-@pytest.mark.parametrize("impl", ["valu", "mfma"])
+@pytest.mark.parametrize("impl", ["valu", "mfma16", "mfma8"])
 def test_creff_vs_oracle(dev, C, Hp, Wp, hp, wp, k, n_cls, logsm, impl, monkeypatch):
     """impl pins one of the two kernels of arseg_creff_fwd (fp32 VALU / split-fp16 matrix cores; the latter falls back to
     the former for shapes it does not cover, e.g. C % 16 != 0 or windows other than 7x7)."""
     from arseg_amd import _lib, ops, synth
 
-    monkeypatch.setenv("ARSEG_CREFF_IMPL", impl)
+    monkeypatch.setenv("ARSEG_CREFF_IMPL", impl[:4])
+    if impl.startswith("mfma"):
+        monkeypatch.setenv("ARSEG_CREFF_TY", impl[4:])          # tile height of the matrix-core kernel (16 / 8 rows)
     from arseg_amd.model import MyAttention
     from arseg_amd.packing import PackedAttention
     from oracle import cpu_ref
