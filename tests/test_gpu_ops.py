@@ -534,3 +534,20 @@ def test_conv2d_f16_reduced_precision(dev):
     finally:
         ops.set_conv_math(prev)
     assert max(errs[:-1]) < 2e-3 and min(errs) > 2e-5 and errs[-1] < 2e-2, errs      # direct ~5e-4; Winograd amplifies it to ~9e-3
+
+
+def test_hw_probe_transpose_read_and_mfma_layout(dev, tmp_path):
+    """Builds and runs ar-seg_amd/csrc/probes/probe_tr.hip: the LDS transpose-read lane semantics and the 16x16x32 fp16 MFMA
+    operand layout that creff_mfma.hip is written against, checked on the actual GPU."""
+    import os
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available on this box")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ar-seg_amd", "csrc", "probes", "probe_tr.hip")
+    exe = str(tmp_path / "probe_tr")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", src, "-o", exe], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stdout + r.stderr
