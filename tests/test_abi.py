@@ -52,6 +52,27 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     d.split_k = 4
     # K = 9*16 = 144 -> 5 K-steps of 32; 4 requested slices -> 2 steps each -> 3 non-empty slices of fp32 partials
     assert lib.arseg_conv2d_workspace_bytes(ctypes.byref(d)) == 3 * ho.value * wo.value * 8 * 4
+    # tile_cfg / math selection: the patch-resident kernel (13..16) covers 3x3 stride-1 pad==dil f16x3 convs with Cin % 32 == 0
+    d.split_k, d.stride, d.pad, d.dil, d.tile_cfg, d.math = 0, 1, 1, 1, 15, _lib.MATH_F16X3
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # Cin = 16
+    d.Cin = d.in_ld = 64
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0
+    d.math = _lib.MATH_F32
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # f16x3 only
+    d.tile_cfg, d.math = 17, _lib.MATH_F16X3
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL
+    d.tile_cfg, d.math = 0, 7
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL
+    # ingest / mergeMotion
+    f3 = (ctypes.c_float * 3)(0.5, 0.5, 0.5)
+    z3 = (ctypes.c_float * 3)(0.5, 0.0, 0.5)
+    assert lib.arseg_frame_u8_to_nhwc4_fwd(null, null, 1, 8, 8, 4, 4, f3, f3, null) == _lib.ARSEG_EINVAL
+    one = ctypes.c_void_p(16)                       # non-null, never dereferenced: validation fails first
+    assert lib.arseg_frame_u8_to_nhwc4_fwd(one, one, 1, 8, 8, 4, 4, f3, z3, null) == _lib.ARSEG_EINVAL                 # zero std
+    assert lib.arseg_merge_motion_workspace_bytes(4, 10, 12) == 5 * 10 * 12 * 16
+    assert lib.arseg_merge_motion_fwd(one, one, one, 0, 4, 0, 10, 12, null) == _lib.ARSEG_EWORKSPACE
+    assert lib.arseg_merge_motion_fwd(one, one, one, 1 << 20, 4, 4, 10, 12, null) == _lib.ARSEG_EINVAL                 # frame_start >= n_frames
+    assert lib.arseg_merge_motion_fwd(null, one, one, 1 << 20, 4, 0, 10, 12, null) == _lib.ARSEG_EINVAL
 
 
 def test_weight_packer_host_functions():
@@ -84,6 +105,31 @@ def test_weight_packer_host_functions():
     o = np.empty((9, C), np.float32)
     assert lib.arseg_pack_dw3x3_host(_hp(dw), C, _hp(o)) == 0
     assert np.array_equal(o, dw.reshape(C, 9).T)
+
+
+def test_split_weight_f16x3_host():
+    """hi + lo (two fp16 per weight, row pre-scaled by a power of two) reproduces the fp32 weight to ~2^-21 of the row maximum."""
+    from arseg_amd import _lib
+
+    def _hp(a):
+        return ctypes.c_void_p(a.ctypes.data)
+
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(17))
+    co, k = 6, 96
+    w = (g.standard_normal((co, k)) * np.array([1e-4, 1e-2, 1.0, 40.0, 3e-7, 0.0])[:, None]).astype(np.float32)
+    out, inv = np.empty((co, k), np.float32), np.empty(co, np.float32)
+    assert lib.arseg_split_weight_f16x3_host(_hp(w), co, k, _hp(out), _hp(inv)) == 0
+    h = out.view(np.float16).reshape(co, k // 32, 2, 32).astype(np.float64)
+    rec = (h[:, :, 0, :] + h[:, :, 1, :]).reshape(co, k) * inv[:, None].astype(np.float64)
+    scale = np.maximum(np.abs(w).max(axis=1, keepdims=True), 1e-30)
+    assert (np.abs(rec - w) / scale).max() <= 2.0 ** -20
+    assert np.all(np.log2(inv) == np.round(np.log2(inv)))                  # exact powers of two (undone in the epilogue scale)
+    assert lib.arseg_split_weight_f16x3_host(_hp(w), co, 40, _hp(out), _hp(inv)) == _lib.ARSEG_EINVAL    # K not a multiple of 32
+    out2 = np.empty((co, k), np.float32)
+    assert lib.arseg_split_weight_f16x3_host(_hp(w), co, k, _hp(out2), ctypes.c_void_p(0)) == 0           # unscaled variant
+    h2 = out2.view(np.float16).reshape(co, k // 32, 2, 32).astype(np.float64)
+    assert np.abs((h2[:, :, 0, :] + h2[:, :, 1, :]).reshape(co, k)[2] - w[2]).max() <= 2.0 ** -20 * np.abs(w[2]).max()
 
 
 def test_module_mirrors_have_the_reference_state_dict(manifest):
