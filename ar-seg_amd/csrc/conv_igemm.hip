@@ -83,12 +83,13 @@ __device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo)
     lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
 }
 
-template <int BM, int BN, int BK, int NBUF, int MATH>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+template <int BM, int BN, int BK, int NBUF, int MATH, int NWM = 2, int NWN = 2>      // NWM x NWN waves, wave tile BM/NWM x BN/NWN
+__global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvParams p) {
     constexpr int LDS_LD = BK + 4;                // floats per LDS row (the +4 pad keeps the ds_read_b128 fragments conflict free)
     constexpr int CPR = BK / 4;                   // 16-byte chunks per row of a K step
-    constexpr int RPP = 256 / CPR;                // rows staged per pass of the 256 threads
-    constexpr int TM = BM / 64, TN = BN / 64;     // 32x32 MFMA tiles per wave (wave tile BM/2 x BN/2)
+    constexpr int NT = 64 * NWM * NWN;
+    constexpr int RPP = NT / CPR;                 // rows staged per pass of the workgroup
+    constexpr int TM = BM / (32 * NWM), TN = BN / (32 * NWN);     // 32x32 MFMA tiles per wave
     constexpr int RA = BM / RPP, RB = BN / RPP;   // rows staged per thread
     constexpr unsigned OOB = 0x80000000u;         // beyond num_records of either buffer: the load returns zeros
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     };
 
     const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int li = lane & 31, lh = lane >> 5;
 
     // f16x3 with a single MFMA tile per wave: a second accumulator for the two cross terms breaks the dependent chain
@@ -213,8 +214,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     auto compute = [&](int cur) {
         if (MATH == ARSEG_MATH_F16) {                  // one fp16 MFMA per product: the hi halves only
-            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
-            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / NWM) + li) * LDS_LD + 4 * lh;
+            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / NWN) + li) * LDS_LD + 4 * lh;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int ko = (ks >> 1) * 32 + (ks & 1) * 8;
@@ -230,8 +231,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
         } else if (MATH == ARSEG_MATH_F16X3) {
             // lane (li, lh) holds k = 16*ks + 8*lh + 0..7 of row li: one ds_read_b128 per operand and precision half
-            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
-            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+            const float *ah = As + cur * BM * LDS_LD + (wm * (BM / NWM) + li) * LDS_LD + 4 * lh;
+            const float *bh = Bs + cur * BN * LDS_LD + (wn * (BN / NWN) + li) * LDS_LD + 4 * lh;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int ko = (ks >> 1) * 32 + (ks & 1) * 8;      // float offset of this 16-k slice inside the row
@@ -269,8 +270,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 }
             }
         } else {
-            const float *a = As + cur * BM * LDS_LD + (wm * (BM / 2) + li) * LDS_LD + 4 * lh;
-            const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / 2) + li) * LDS_LD + 4 * lh;
+            const float *a = As + cur * BM * LDS_LD + (wm * (BM / NWM) + li) * LDS_LD + 4 * lh;
+            const float *b = Bs + cur * BN * LDS_LD + (wn * (BN / NWN) + li) * LDS_LD + 4 * lh;
 #pragma unroll
         for (int k8 = 0; k8 < BK / 8; ++k8) {
             f32x4 fa[TM], fb[TN];
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
         for (int tn = 0; tn < TN; ++tn) {
-            const int n = n0 + wn * (BN / 2) + tn * 32 + li;
+            const int n = n0 + wn * (BN / NWN) + tn * 32 + li;
             if (n >= p.Cout) continue;
             float sc = 1.0f, bi = 0.0f;
             if (p.nsplit == 1) {
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (BM / 2) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = m0 + wm * (BM / NWM) + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= p.M) continue;
                 float v = acc[tm][tn][r];
                 if (p.nsplit == 1) {
@@ -574,9 +575,10 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->M = (int)M;
     pl->K = d->R * d->S * d->Cin;
     pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
-    if (d->tile_cfg < 0 || d->tile_cfg > 16) return ARSEG_EINVAL;
+    if (d->tile_cfg < 0 || d->tile_cfg > 19) return ARSEG_EINVAL;
     pl->patch_tw = 0;
-    if (d->tile_cfg >= 13) {          // patch-resident 3x3 kernel: 128 (13, 14) / 256 (15, 16) pixel tiles TH x TW of one image, BN = 64 / 128
+    if (d->tile_cfg >= 17 && d->math != ARSEG_MATH_F16X3) return ARSEG_EUNSUPPORTED;      // the large tiles are built for f16x3 only
+    if (d->tile_cfg >= 13 && d->tile_cfg <= 16) {          // patch-resident 3x3 kernel: 128 (13, 14) / 256 (15, 16) pixel tiles TH x TW of one image, BN = 64 / 128
         if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || d->math != ARSEG_MATH_F16X3 || (d->Cin & 31) || d->batch > 1 ||
             d->split_k > 1)
             return ARSEG_EUNSUPPORTED;
@@ -592,14 +594,15 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
         pl->tiles_n = arseg_cdiv(d->Cout, pl->bn);
         return ARSEG_OK;
     }
-    pl->bk = d->tile_cfg >= 9 ? 64 : 32;
+    pl->bk = (d->tile_cfg >= 9 && d->tile_cfg <= 12) ? 64 : 32;
     pl->ktiles = (pl->Kpad + pl->bk - 1) / pl->bk;
     // operands are addressed through 32-bit buffer offsets
     if (((long long)d->N * d->H * d->W * d->in_ld + d->Cin) * 4 >= (1ll << 31) || (long long)d->Cout * pl->Kpad * 4 >= (1ll << 31))
         return ARSEG_EUNSUPPORTED;
 
-    static const int cfg[13][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 128},
-                                   {128, 128}, {128, 64}, {64, 64}, {64, 128}};
+    static const int cfg[20][2] = {{0, 0}, {128, 128}, {128, 64}, {64, 64}, {64, 128}, {128, 128}, {128, 64}, {64, 64}, {64, 128},
+                                   {128, 128}, {128, 64}, {64, 64}, {64, 128}, {0, 0}, {0, 0}, {0, 0}, {0, 0},
+                                   {256, 128}, {128, 256}, {256, 256}};       // 17..19: 8- / 16-wave tiles (more reuse per byte from L2 / MALL)
     // Tile / split-K choice, fitted to a brute-force sweep of this model family's layer shapes on MI355X
     // (scratch sweep recorded in DESIGN.md): aim for ~512 workgroups (2 per CU); take the largest tile that gets
     // there with a split-K factor that still leaves >= 8 K-steps per slice; shallow GEMMs (< 64 K-steps) are best
@@ -643,18 +646,18 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     return ARSEG_OK;
 }
 
-template <int BM, int BN, int BK, int NBUF, int MATH>
+template <int BM, int BN, int BK, int NBUF, int MATH, int NWM = 2, int NWN = 2>
 int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
     const size_t smem = (size_t)NBUF * (BM + BN) * (BK + 4) * sizeof(float);
     static bool attr_set = false;     // idempotent; a race only repeats the same call
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, BK, NBUF, MATH>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, BK, NBUF, MATH, NWM, NWN>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     dim3 grid(pl.tiles_m * pl.tiles_n, p.in_bs || p.w_bs || p.out_bs ? p.N_batch : 1, pl.nsplit);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, NBUF, MATH>), grid, dim3(256), smem, st, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, NBUF, MATH, NWM, NWN>), grid, dim3(64 * NWM * NWN), smem, st, p);
     return arseg_launch_status();
 }
 
@@ -684,6 +687,11 @@ int launch_patch(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
 
 template <int MATH>
 int launch_math(const ConvParams &p, const Plan &pl, hipStream_t hs) {
+    if (MATH == ARSEG_MATH_F16X3 && (pl.bm == 256 || pl.bn == 256)) {
+        if (pl.bm == 256 && pl.bn == 128) return launch<256, 128, 32, 1, ARSEG_MATH_F16X3, 4, 2>(p, pl, hs);
+        if (pl.bm == 128 && pl.bn == 256) return launch<128, 256, 32, 1, ARSEG_MATH_F16X3, 2, 4>(p, pl, hs);
+        return launch<256, 256, 32, 1, ARSEG_MATH_F16X3, 4, 4>(p, pl, hs);
+    }
     if (pl.bk == 64) return launch_tile<64, 1, MATH>(p, pl, hs);
     return pl.nbuf == 1 ? launch_tile<32, 1, MATH>(p, pl, hs) : launch_tile<32, 2, MATH>(p, pl, hs);
 }

@@ -333,9 +333,11 @@ def _conv_candidates(ktiles: int, cout: int, m: int, patch_ok: bool = False):
     cands = []
     if patch_ok:                                   # patch-resident 3x3 kernel (13/14: 128-pixel tiles, 15/16: 256; BN 64/128)
         cands += [(15, 1), (13, 1)] + ([(16, 1), (14, 1)] if cout > 64 else [])
-    for cfg in (5, 6, 7, 8, 9, 10, 11, 12):
-        bn = 128 if cfg in (5, 8, 9, 12) else 64
-        bm = 128 if cfg in (5, 6, 9, 10) else 64
+    for cfg in (5, 6, 7, 8, 9, 10, 11, 12) + ((17, 18, 19) if _math == _lib.MATH_F16X3 else ()):
+        bn = {17: 128, 18: 256, 19: 256}.get(cfg, 128 if cfg in (5, 8, 9, 12) else 64)
+        bm = {17: 256, 18: 128, 19: 256}.get(cfg, 128 if cfg in (5, 6, 9, 10) else 64)
+        if bn >= 128 and cfg >= 17 and cout < bn:
+            continue
         if bn == 128 and cout <= 64:
             continue
         if bm == 128 and m <= 64:
@@ -469,8 +471,10 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
 
     if plan is None:
         best, best_t = 0, float("inf")
-        for cfg in (0, 5, 6, 7, 8, 9, 10, 11, 12):
-            if cfg in (5, 8, 9, 12) and Cout <= 64:
+        for cfg in (0, 5, 6, 7, 8, 9, 10, 11, 12) + ((17, 18, 19) if math == _lib.MATH_F16X3 else ()):
+            if cfg in (5, 8, 9, 12, 17, 18, 19) and Cout <= 64:
+                continue
+            if cfg in (18, 19) and Cout <= 128:
                 continue
             t = _time(lambda: gemm(cfg, False))
             if t < best_t:

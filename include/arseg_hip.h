@@ -122,7 +122,8 @@ typedef struct arseg_conv_desc {
                           same tiles single-buffered (half the LDS, more workgroups per CU); 9..12 = single-buffered, K step 64;
                           13..16 = patch-resident kernel for 3x3 stride-1 pad==dil convs under ARSEG_MATH_F16X3 (Cin % 32 == 0): the
                           input patch of a 128- (13, 14) or 256-pixel (15, 16) tile stays in LDS for all nine taps, BN = 64 / 128;
-                          ARSEG_EUNSUPPORTED for other shapes */
+                          ARSEG_EUNSUPPORTED for other shapes; 17..19 = 256x128, 128x256, 256x256 tiles on 8 / 16 waves (F16X3 only):
+                          more MFMA work per byte fetched from L2 / Infinity Cache, for wide GEMMs that fill the chip */
     int split_k;       /* 0 auto, >= 1 explicit */
     /* batched mode (used by the Winograd path): `batch` independent problems of identical shape, problem b reads
        in + b*in_batch_stride, w_packed + b*w_batch_stride and writes out + b*out_batch_stride (strides in floats);
