@@ -59,7 +59,9 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == 0
     d.math = _lib.MATH_F32
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # f16x3 only
-    d.tile_cfg, d.math = 17, _lib.MATH_F16X3
+    d.tile_cfg, d.math = 17, _lib.MATH_F32
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # 8/16-wave tiles: f16x3 only
+    d.tile_cfg, d.math = 20, _lib.MATH_F16X3
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL
     d.tile_cfg, d.math = 0, 7
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL
