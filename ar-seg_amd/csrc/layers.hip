@@ -113,6 +113,40 @@ __global__ __launch_bounds__(256) void resize_nhwc_kernel(const float *__restric
     }
 }
 
+// Exact x2 bilinear upsample with align_corners=False (F.upsample's default: PSPUpsample, model/pspnet.py:45): the source
+// offsets are the constants 0.25 / 0.75, so one thread turns a 3x3 low-resolution neighbourhood (clamped at the border, which
+// reproduces ATen's src < 0 -> 0 and i1 = min(i0+1, h-1)) into the 2x2 outputs of its pixel: no per-element index divisions,
+// every loaded vector feeds four outputs.  grid = (ceil(Win*C/4 / 256), Hin, N).
+__global__ __launch_bounds__(256) void upsample2x_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int C, int Hin, int Win,
+                                                              int in_ld, int out_ld) {
+    const int c4n = C >> 2, t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= Win * c4n) return;
+    const int j = t / c4n, c = (t - j * c4n) * 4, i = blockIdx.y, n = blockIdx.z;
+    const float *base = in + (size_t)n * Hin * Win * in_ld + c;
+    f32x4 L[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int y = min(max(i - 1 + a, 0), Hin - 1);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) L[a][b] = *reinterpret_cast<const f32x4 *>(base + ((size_t)y * Win + min(max(j - 1 + b, 0), Win - 1)) * in_ld);
+    }
+    f32x4 r[2][3];                                     // the two output rows, still at the three low-resolution columns
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        r[0][b] = (i > 0) ? 0.25f * L[0][b] + 0.75f * L[1][b] : L[1][b];            // src = i - 0.25: (1-l) L[i-1] + l L[i], l = 0.75
+        r[1][b] = 0.75f * L[1][b] + 0.25f * L[2][b];                                // src = i + 0.25 (L[2] is L[1] again on the last row)
+    }
+    const int Wout = 2 * Win;
+    float *o = out + ((size_t)n * 2 * Hin + 2 * i) * Wout * out_ld + (size_t)(2 * j) * out_ld + c;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const f32x4 left = (j > 0) ? 0.25f * r[a][0] + 0.75f * r[a][1] : r[a][1];
+        const f32x4 right = 0.75f * r[a][1] + 0.25f * r[a][2];
+        *reinterpret_cast<f32x4 *>(o + (size_t)a * Wout * out_ld) = left;
+        *reinterpret_cast<f32x4 *>(o + (size_t)a * Wout * out_ld + out_ld) = right;
+    }
+}
+
 __global__ __launch_bounds__(256) void resize_nchw_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin,
                                                           int Win, int Hout, int Wout, int mode, int align) {
     const long long total = (long long)NC * Hout * Wout;
@@ -453,6 +487,11 @@ extern "C" int arseg_resize_fwd(const float *in, float *out, int N, int C, int H
     if (mode != ARSEG_NEAREST && mode != ARSEG_BILINEAR) return ARSEG_EINVAL;
     if (layout == ARSEG_NHWC) {
         if ((C & 3) || (in_ld & 3) || (out_ld & 3) || in_ld < C || out_ld < C) return ARSEG_EINVAL;
+        if (mode == ARSEG_BILINEAR && !align_corners && Hout == 2 * Hin && Wout == 2 * Win && Hin <= 65535 && N <= 65535) {
+            hipLaunchKernelGGL(upsample2x_nhwc_kernel, dim3(arseg_cdiv((long long)Win * (C >> 2), 256), Hin, N), dim3(256), 0, arseg_stream(stream),
+                               in, out, C, Hin, Win, in_ld, out_ld);
+            return arseg_launch_status();
+        }
         hipLaunchKernelGGL(resize_nhwc_kernel, dim3(grid_for((long long)N * Hout * Wout * (C >> 2))), dim3(256), 0,
                            arseg_stream(stream), in, out, N, C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0, in_ld, out_ld);
     } else if (layout == ARSEG_NCHW) {

@@ -553,3 +553,20 @@ def test_hw_probe_transpose_read_and_mfma_layout(dev, tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", src, "-o", exe], check=True, capture_output=True, timeout=300)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 9, 13, 64), (1, 1, 1, 8), (1, 1, 7, 4), (1, 6, 1, 12), (1, 32, 64, 64)])
+def test_upsample2x_fast_path(dev, N, H, W, C):
+    """The dedicated x2 bilinear (align_corners=False) kernel behind resize_nhwc, incl. degenerate sizes and a strided
+    (channel-slice) destination."""
+    from arseg_amd import _lib, ops
+
+    x = rnd(97, N, C, H, W)
+    want = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.resize_nhwc(xd, 2 * H, 2 * W, _lib.BILINEAR, False)
+    assert maxdiff(got.permute(0, 3, 1, 2), want) <= 1e-6
+    big = torch.full((N, 2 * H, 2 * W, C + 8), 3.0, device=dev)
+    ops.resize_nhwc(xd, 2 * H, 2 * W, _lib.BILINEAR, False, out=big[..., 4:4 + C])
+    assert maxdiff(big[..., 4:4 + C].permute(0, 3, 1, 2), want) <= 1e-6
+    assert float(big[..., :4].min()) == 3.0 and float(big[..., 4 + C:].max()) == 3.0
