@@ -42,10 +42,10 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
 // block = (bin, 16-channel chunk, n); 256 threads = 64 pixel lanes x 4 channel vectors; fixed-order LDS tree over the
 // pixel lanes (deterministic).  Small chunks keep many blocks in flight for the whole-image bins (1x1 pyramid level,
 // global mean / max), which are pure streaming reads.
-template <bool IS_MAX>
-__global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
-                                                            int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow) {
-    __shared__ f32x4 red[64][5];
+template <bool IS_MAX, int PL = 64>      // PL pixel lanes x 4 channel vectors: 256 threads, or 1024 for launches with few blocks
+__global__ __launch_bounds__(4 * PL) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
+                                                               int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow) {
+    __shared__ f32x4 red[PL][5];
     const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
     const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
     const int x0 = (bx * W) / ow, x1 = ((bx + 1) * W + ow - 1) / ow;
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restr
     const int ww = x1 - x0, cnt = (y1 - y0) * ww;
     f32x4 acc = IS_MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        for (int i = pl; i < cnt; i += 64) {
+        for (int i = pl; i < cnt; i += PL) {
             const int yy = y0 + i / ww, xx = x0 + i % ww;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(in + (((size_t)n * H + yy) * W + xx) * in_ld + c);
             if (IS_MAX) { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void window_reduce_kernel(const float *__restr
     red[pl][cv] = acc;
     __syncthreads();
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) {
+    for (int s = PL / 2; s >= 1; s >>= 1) {
         if (pl < s) {
             const f32x4 o = red[pl + s][cv];
             f32x4 t = red[pl][cv];
@@ -445,8 +445,11 @@ extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out
     if (out_ld == 0) out_ld = C;
     if (out_n_stride == 0) out_n_stride = (long long)oh * ow * out_ld;
     if ((out_ld & 3) || out_ld < C || (out_n_stride & 3) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
-    hipLaunchKernelGGL(window_reduce_kernel<false>, dim3(oh * ow, arseg_cdiv(C, 16), N), dim3(256), 0, arseg_stream(stream), in,
-                       in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
+    const dim3 grid(oh * ow, arseg_cdiv(C, 16), N);
+    if ((long long)grid.x * grid.y * grid.z < 256)          // few, large windows (1x1 / 2x2 pyramid levels): 4x the pixel lanes per block
+        hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
+    else
+        hipLaunchKernelGGL((window_reduce_kernel<false, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
     return arseg_launch_status();
 }
 
@@ -472,11 +475,14 @@ extern "C" int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, i
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
     if ((C & 3) || (in_ld & 3) || in_ld < C) return ARSEG_EINVAL;
     dim3 grid(1, arseg_cdiv(C, 16), N);
-    if (op == ARSEG_REDUCE_MEAN)
-        hipLaunchKernelGGL(window_reduce_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
-    else if (op == ARSEG_REDUCE_MAX)
-        hipLaunchKernelGGL(window_reduce_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
-    else return ARSEG_EINVAL;
+    const bool big = (long long)grid.y * grid.z < 256;
+    if (op == ARSEG_REDUCE_MEAN) {
+        if (big) hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
+        else hipLaunchKernelGGL((window_reduce_kernel<false, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
+    } else if (op == ARSEG_REDUCE_MAX) {
+        if (big) hipLaunchKernelGGL((window_reduce_kernel<true, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
+        else hipLaunchKernelGGL((window_reduce_kernel<true, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, C, (long long)C, H, W, C, 1, 1);
+    } else return ARSEG_EINVAL;
     return arseg_launch_status();
 }
 
