@@ -264,6 +264,50 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
     return p_out, logits
 
 
+def creff_warp(refs_nhwc, mv_q: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softmax: bool = False, kH: int = 7,
+               kW: int = 7, p_layout: int = _lib.C8) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """MV warp + CReFF + head in one kernel (arseg_creff_warp_fwd).
+
+    refs_nhwc: sequence of B un-warped keyframe features, NHWC [Hp,Wp,C] each (frames of one GOP share theirs);
+    mv_q: int16 [B,H,W,2]; lr_nhwc: [B,hp,wp,C].  Returns (p in ``p_layout``, logits NCHW or None).  Shapes the fused
+    kernel does not cover (C != 64, windows other than 7x7) run as arseg_warp_mvq_fwd + arseg_creff_fwd."""
+    _need_gpu(lr_nhwc, *refs_nhwc)
+    _need_gpu(mv_q, dtype=torch.int16)
+    lr_nhwc, mv_q = lr_nhwc.contiguous(), mv_q.contiguous()
+    B, hp, wp, C = lr_nhwc.shape
+    refs = [r.contiguous() for r in refs_nhwc]
+    Hp, Wp, C2 = refs[0].shape
+    _, H, W, _ = mv_q.shape
+    if len(refs) != B or mv_q.shape[0] != B or C2 != C or any(tuple(r.shape) != (Hp, Wp, C) for r in refs):
+        raise _lib.ArsegError("creff_warp: refs / mv_q / lr batch or channel mismatch")
+    fused_ok = C == 64 and kH == 7 and kW == 7 and (head is None or head[0].shape[0] <= 32) and C * Hp * Wp * 4 < (1 << 31)
+    if not fused_ok:
+        ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=lr_nhwc.device)
+        for b in range(B):
+            warp_mvq(refs[b].unsqueeze(0), mv_q[b:b + 1], _lib.C8, out=ref_c8[b:b + 1])
+        p_c8, logits = creff(ref_c8, lr_nhwc, attn, head, log_softmax, kH, kW)
+        return (p_c8 if p_layout == _lib.C8 else from_c8(p_c8, _lib.NHWC)), logits
+    per = max(1, min(32, ((1 << 31) - 1) // (C * Hp * Wp * 4)))          # frames per launch: 32-bit buffer offsets, 32 pointers
+    if B > per:
+        outs = [creff_warp(refs[i:i + per], mv_q[i:i + per], lr_nhwc[i:i + per], attn, head, log_softmax, kH, kW, p_layout)
+                for i in range(0, B, per)]
+        return torch.cat([o[0] for o in outs]), (None if outs[0][1] is None else torch.cat([o[1] for o in outs]))
+    shape = (B, C // 8, Hp, Wp, 8) if p_layout == _lib.C8 else (B, Hp, Wp, C)
+    p_out = torch.empty(shape, dtype=torch.float32, device=lr_nhwc.device)
+    logits, wf, bf, n_cls = None, None, None, 0
+    if head is not None:
+        wf, bf = head
+        n_cls = wf.shape[0]
+        logits = torch.empty((B, n_cls, Hp, Wp), dtype=torch.float32, device=lr_nhwc.device)
+    ptrs = (ctypes.c_void_p * B)(*[r.data_ptr() for r in refs])
+    _launch("creff_warp", _lib.load().arseg_creff_warp_fwd, ptrs, _ptr(mv_q), H, W, _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq),
+            _ptr(attn.wk), _ptr(attn.bk), _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), p_layout, _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
+            1 if log_softmax else 0, B, C, Hp, Wp, hp, wp, kH, kW, _stream(),
+            flops=B * Hp * Wp * C * (250 + 2 * n_cls),
+            nbytes=B * (4 * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp) + 4 * H * W))
+    return p_out, logits
+
+
 # ----------------------------------------------------------------------------------------------
 # conv engine
 # ----------------------------------------------------------------------------------------------

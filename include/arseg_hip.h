@@ -98,6 +98,27 @@ int arseg_creff_fwd(const float *hr, const float *lr, const float *wq, const flo
                     int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH,
                     int kW, arseg_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * warpFeature + MyAttention.forward + final 1x1 classifier in ONE kernel (the non-keyframe tail of
+ * EvalAlterRes, evaluation.py:176-193, for the 64-channel full-resolution PSPNet feature):
+ *                                   evaluation.py:61-87,176-180; model/attention.py:184-213;
+ *                                   model/pspnet.py:219-231
+ * The keyframe feature is read UN-warped and sampled with the frame's motion vectors while a tile
+ * is staged, so the warped tensor never exists in memory.
+ *   ref_nhwc_host : HOST array of N device pointers; entry i = keyframe feature of frame i,
+ *                   NHWC [Hp][Wp][C] (ld == C).  Frames of one GOP pass the same pointer.
+ *   mv_q : int16 quarter-pel [N,H,W,2] as in arseg_warp_mvq_fwd (resized to (Hp,Wp) in fp64 in-kernel)
+ *   lr, wq..bv, wf, bf, logits, log_softmax : as arseg_creff_fwd
+ *   p_out : the fused feature, layout p_layout = ARSEG_C8 [N,C/8,Hp,Wp,8] or ARSEG_NHWC [N,Hp,Wp,C]
+ * Supported: C == 64, kH == kW == 7, N <= 32, n_cls <= 32, N*C*Hp*Wp*4 < 2 GiB; anything else
+ * returns ARSEG_EUNSUPPORTED and the caller uses arseg_warp_mvq_fwd + arseg_creff_fwd.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
+                         const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
+                         const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
+                         float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
+                         arseg_stream_t stream);
+
 /* Layout changes to / from C8 at the API boundary (layout = ARSEG_NCHW or ARSEG_NHWC; ld = NHWC channel stride). */
 int arseg_to_c8_fwd(const float *in, int layout, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);
 int arseg_from_c8_fwd(const float *in, float *out, int layout, int out_ld, int N, int C, int HW, arseg_stream_t stream);

@@ -570,3 +570,52 @@ def test_upsample2x_fast_path(dev, N, H, W, C):
     ops.resize_nhwc(xd, 2 * H, 2 * W, _lib.BILINEAR, False, out=big[..., 4:4 + C])
     assert maxdiff(big[..., 4:4 + C].permute(0, 3, 1, 2), want) <= 1e-6
     assert float(big[..., :4].min()) == 3.0 and float(big[..., 4 + C:].max()) == 3.0
+
+
+# ---------------------------------------------------------------------------------------------- warp + CReFF fused (C = 64)
+@pytest.mark.parametrize("Hp,Wp,hp,wp,n_cls,logsm,layout", [
+    (40, 70, 20, 35, 12, True, "c8"),       # ragged vs the 16x16 tile
+    (16, 16, 8, 8, 12, True, "nhwc"),       # exactly one tile
+    (33, 47, 17, 24, 19, False, "c8"),      # odd sizes, two classifier row blocks
+    (7, 9, 7, 9, 0, False, "nhwc"),         # image smaller than a tile, same-size lr, no head
+    (64, 96, 32, 48, 12, True, "c8"),       # several tiles in both directions
+])
+def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout):
+    """arseg_creff_warp_fwd (MV warp fused into the CReFF tile staging) against the oracle's warp -> MyAttention -> head and,
+    bit for the warp / tolerance for the rest, against the two-kernel path (arseg_warp_mvq_fwd + arseg_creff_fwd)."""
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+    from oracle import cpu_ref
+
+    C, N = 64, 3
+    g = np.random.Generator(np.random.PCG64(31))
+    for gain in (0.35, 1.0):
+        m = synth.load_synth_weights(MyAttention(C, kW=7, kH=7), 7, attn_gain=gain)
+        sd = {kk: v.clone() for kk, v in m.state_dict().items()}
+        refs = [rnd(40, C, Hp, Wp), rnd(41, C, Hp, Wp)]
+        refs = [refs[0], refs[1], refs[0]]                      # frames 0 and 2 share a keyframe
+        lr = rnd(42, N, C, hp, wp)
+        mvq = torch.from_numpy((g.integers(-9, 10, (N, Hp, Wp, 2)) * 4).astype(np.int16))
+        mvq[1, : Hp // 2] = mvq[1, 0, 0]                        # a block-constant region
+        mvq[2, :, : Wp // 3, 0] = 4 * (Wp + 5)                  # samples far outside the image -> zeros
+        hr_w = torch.cat([cpu_ref.warp_feature(refs[i][None], cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq[i:i + 1]), Hp, Wp)) for i in range(N)])
+        want = cpu_ref.my_attention(sd, "", hr_w, lr, 7, 7)
+        pa = PackedAttention(m, dev)
+        head = None
+        if n_cls:
+            wf, bf = rnd(22, n_cls, C, scale=0.2), rnd(23, n_cls, scale=0.1)
+            head = (wf.to(dev), bf.to(dev))
+        refs_d = [r.permute(1, 2, 0).contiguous().to(dev) for r in refs]
+        lay = _lib.C8 if layout == "c8" else _lib.NHWC
+        p, logits = ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, head, logsm, 7, 7, p_layout=lay)
+        got = ops.from_c8(p, _lib.NCHW) if layout == "c8" else p.permute(0, 3, 1, 2)
+        tol = 1e-4 if gain < 1 else 3e-4
+        assert maxdiff(got, want) <= tol
+        if n_cls:
+            lg = F.conv2d(want, wf[:, :, None, None], bf)
+            if logsm:
+                lg = F.log_softmax(lg, dim=1)
+            assert maxdiff(logits, lg) <= 2 * tol
+        else:
+            assert logits is None
