@@ -42,10 +42,9 @@ constexpr int LW = 18, LN = 324, LPL = 329;          // lr_up tile (+1 halo) per
 constexpr int BIG_BYTES = 16 * HPL * 16;             // 147,712: staged region / lr_up tile / key records / value records
 constexpr int TAPW_OFF = BIG_BYTES;                  // [576] {ex, wx, ey, wy} with the tap validity folded in (0 = tap outside)
 constexpr int TAPO_OFF = TAPW_OFF + R4N * 16;        // [576] pixel index of the NW tap | dx << 30 | dy << 31 (clamped taps)
-constexpr int WFS_OFF = TAPW_OFF;                    // classifier records alias the tap tables (dead after the gather)
-constexpr int TB_OFF = TAPO_OFF + R4N * 4;           // [18 rows + 18 cols] bilinear taps of the lr_up tile
-constexpr int WDQ_OFF = TB_OFF + 2 * LW * 16;        // [4 chunks][9 taps + bias][4 groups] query conv weights
-constexpr int SMEM_BYTES = WDQ_OFF + 4 * 10 * 4 * 16;   // 162,368 <= 163,840
+constexpr int WFS_OFF = 16 * KPLV * 16;              // classifier records: behind the value records, inside BIG (128,000 + 8 KB <= 147,712)
+constexpr int WDQ_OFF = TAPO_OFF + R4N * 4;          // [4 chunks][9 taps + bias][4 groups] query conv weights
+constexpr int SMEM_BYTES = WDQ_OFF + 4 * 10 * 4 * 16;   // 161,792 <= 163,840
 constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
@@ -55,9 +54,10 @@ struct RRParams {
     const int16_t *mv;            // [N][H][W][2] quarter-pel
     const float *lr, *wq, *bq, *wk, *bk, *wv, *bv, *wf, *bf;
     float *p_out, *logits;
-    int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout;
+    int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout, tiles_x, tiles_y;
     unsigned p_bytes, l_bytes;
     float sy, sx;
+    unsigned long long *dbg;
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
@@ -83,16 +83,31 @@ __device__ __forceinline__ f32x4 dpp4(const f32x4 v) {     // row_shr:1 = 0x111 
     for (int j = 0; j < 4; ++j) r[j] = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v[j]), CTRL, 0xF, 0xF, true));
     return r;
 }
-__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, f32x4 c) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = fmaf(a[j], b[j], c[j]);
-    return c;
+// a * b + c on packed pairs: v_pk_fma_f32 issues 2 FMAs in 4.2 cycles per wave, v_fmac_f32 one in 3.0 (measured on MI355X, 4 waves
+// per SIMD) -- the depthwise convolutions are bound by exactly this
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, const f32x4 c) {
+    const f32x2 lo = __builtin_elementwise_fma(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), __builtin_shufflevector(c, c, 0, 1));
+    const f32x2 hi = __builtin_elementwise_fma(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), __builtin_shufflevector(c, c, 2, 3));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3);
 }
-// record index (row-major in the 22 x 22 record region) of flat window key f (0..111) of the patch at (pc, pr)
-__device__ __forceinline__ int key_rec(int f, int pc, int pr) {
-    const int ky = (f * 147) >> 11, kx = f - 14 * ky;        // f / 14 for f < 112
-    return (2 * pr + ky) * R3W + 8 * pc + kx;
-}
+// Record index (row-major in the 22 x 22 record region) of flat window key f = 16b + k0 (k0 in 0..15) of the patch at (pc, pr).
+// The window is 8 rows x 14 columns: f = 14 ky + kx.  With e = 2b + k0 (< 28): ky = b + (e >= 14), kx = e - 14 (e >= 14), so
+// rec = (2pr + ky) * 22 + 8pc + kx = [44 pr + 8 pc + k0] + 24 b + 8 (k0 >= 14 - 2b): one compare-select per block.
+__device__ __forceinline__ int key_rec(int b, int k0, int base0) { return base0 + 24 * b + (k0 >= 14 - 2 * b ? 8 : 0); }
+
+#ifdef RR_TIMING
+// dev builds only: wave 0 adds the shader-clock ticks since its previous stamp to dbg[i] (scalar registers, one atomic)
+#define RR_STAMP(i) do { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        if (tid0 == 0 && p.dbg) atomicAdd(p.dbg + (i), now_ - tprev_); tprev_ = now_; } } while (0)
+#else
+#define RR_STAMP(i) do { } while (0)
+#endif
+#ifdef RR_ABLATE
+#define RR_ON(bit) (!((RR_ABLATE >> (bit)) & 1) || p.N > 1000000)
+#else
+#define RR_ON(bit) true
+#endif
 
 template <int NB>      // NB: classifier row blocks of 16 classes (0: no head)
 __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
@@ -103,171 +118,200 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     f32x4 *TapW = reinterpret_cast<f32x4 *>(smem + TAPW_OFF);
     unsigned *TapO = reinterpret_cast<unsigned *>(smem + TAPO_OFF);
     f32x4 *Wfs = reinterpret_cast<f32x4 *>(smem + WFS_OFF);        // [4 chunks][4 groups][NBA*16] {4 hi | 4 lo}
-    f32x4 *Tb = reinterpret_cast<f32x4 *>(smem + TB_OFF);
     f32x4 *WdQ = reinterpret_cast<f32x4 *>(smem + WDQ_OFF);
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int q = lane & 15, g = lane >> 4, qy = q >> 3, qx = q & 7;
-    const int pc = wave & 1, pr = wave >> 1;
-    // XCD-aware tile order (workgroup ids go round-robin to the 8 XCDs; give each XCD a contiguous run of tiles so that the
-    // halos neighbouring tiles share are fetched into one L2)
-    int n, ty0, tx0;
-    {
-        const int tiles_x = gridDim.x, per_img = gridDim.x * gridDim.y, nblk = per_img * gridDim.z;
-        int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        const int qn = nblk >> 3, rn = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + idx;
-        n = bid / per_img;
-        const int rem = bid - n * per_img;
-        ty0 = (rem / tiles_x) * TY; tx0 = (rem - (rem / tiles_x) * tiles_x) * TX;
-    }
-    const int Hp = p.Hp, Wp = p.Wp;
-    const int yq = 2 * pr + qy, xq = 8 * pc + qx;               // this lane's query pixel, tile relative
-    const int gyq = ty0 + yq, gxq = tx0 + xq;
-
-    // ------------------------------------------------------------------ phase 0: sampling taps of the region, lr_up tables, query weights
-    if (tid < R4N) {
-        const int yr = tid / R4W, xr = tid - yr * R4W;
-        const int gy = ty0 - 4 + yr, gx = tx0 - 4 + xr;
-        f32x4 w = {0.f, 0.f, 0.f, 0.f};
-        unsigned o = 0;
-        if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp) {      // outside the image the region is zero (conv padding)
-            double fx, fy;
-            const int16_t *mvn = p.mv + (size_t)n * p.H * p.W * 2;
-            if (Hp == p.H && Wp == p.W) {          // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
-                const int16_t *m = mvn + ((size_t)gy * p.W + gx) * 2;
-                fx = (double)m[0] / 4.0; fy = (double)m[1] / 4.0;
-            } else {
-                mv_at(mvn, p.H, p.W, Hp, Wp, gy, gx, fx, fy);
-            }
-            float ngx, ngy;
-            norm_grid<double>(gx, gy, fx, fy, Hp, Wp, ngx, ngy);
-            const Taps t = make_taps(ngx, ngy, Hp, Wp);
-            const int xa = min(max(t.x0, 0), Wp - 1), xc = min(max(t.x0 + 1, 0), Wp - 1);
-            const int ya = min(max(t.y0, 0), Hp - 1), yc = min(max(t.y0 + 1, 0), Hp - 1);
-            o = (unsigned)(ya * Wp + xa) | ((unsigned)(xc - xa) << 30) | ((unsigned)(yc - ya) << 31);
-            w = f32x4{t.vx0 ? t.ex : 0.f, t.vx1 ? t.wx : 0.f, t.vy0 ? t.ey : 0.f, t.vy1 ? t.wy : 0.f};
-        }
-        TapW[tid] = w; TapO[tid] = o;
-    } else if (tid < R4N + 2 * LW) {
-        // bilinear(align_corners=True) taps of the lr_up tile rows / columns (tile coordinate -1 .. 16):
-        // {lr index of tap 0 (rows: * wp), of tap 1, weight of tap 1, inside the image}
-        const int e = tid - R4N;
-        const bool row = e < LW;
-        const int rel = row ? e : e - LW;
-        const int gc = (row ? ty0 : tx0) - 1 + rel, lim = row ? Hp : Wp;
-        int i0, i1; float l1;
-        arseg_src_index(row ? p.sy : p.sx, min(max(gc, 0), lim - 1), true, row ? p.hp : p.wp, i0, i1, l1);
-        l1 = fminf(fmaxf(l1, 0.f), 1.f);
-        Tb[e] = f32x4{__int_as_float(row ? i0 * p.wp : i0), __int_as_float(row ? i1 * p.wp : i1), l1, (unsigned)gc < (unsigned)lim ? 1.0f : 0.0f};
-    } else if (tid >= 640 && tid < 640 + 160) {
-        const int e = tid - 640, gg = e & 3, tp = (e >> 2) % 10, c = e / 40;
+    const int tid0 = threadIdx.x;
+    // Persistent workgroups (one per CU: 158 KB of LDS): each walks its share of the tiles, so the 16-wave launch latency is paid
+    // once.  XCD-aware order: workgroup ids go round-robin to the 8 XCDs (private L2s); XCD x owns a contiguous run of tiles and
+    // its workgroups take neighbouring tiles at the same time, so the halos they share are fetched into one L2 once.
+    const int per_img = p.tiles_x * p.tiles_y, ntiles = per_img * p.N;
+    const int nx = min(8, (int)gridDim.x);                  // (fewer than 8 workgroups: one tile run per workgroup)
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx, nslot = ((int)gridDim.x - xcd + nx - 1) / nx;
+    const int t_lo = (int)((long long)ntiles * xcd / nx), t_hi = (int)((long long)ntiles * (xcd + 1) / nx);
+    if (tid0 >= 640 && tid0 < 640 + 160) {           // query conv weights: the same for every tile
+        const int e = tid0 - 640, gg = e & 3, tp = (e >> 2) % 10, c = e / 40;
         const float *src = tp < 9 ? p.wq + (size_t)tp * CH + c * 16 + gg * 4 : p.bq + c * 16 + gg * 4;
         WdQ[e] = *reinterpret_cast<const f32x4 *>(src);
     }
-    __syncthreads();
-
-    // ------------------------------------------------------------------ phase 1: gather + bilinear warp of the region into LDS
-    // unit = (region pixel, channel group): 16 lanes read one whole 256-byte pixel per tap
+    // which of a lane's 28 score slots are real window taps: slot (b, i) is key f = 16b + 4g + i = (ky, kx) of the 8 x 14 patch
+    // window; real iff ky - qy and kx - qx both lie in [0, 6].  A per-lane constant: one bit per slot.
+    unsigned okmask = 0;
     {
-        const float *img = p.ref[n];
-        const int g16 = tid & 15, pl = tid >> 4;
-        const unsigned row_off = (unsigned)Wp * CH;
-#pragma unroll 1
-        for (int k0 = 0; k0 < 9; k0 += 3) {
-            f32x4 v[3][4], w[3];
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int pix = pl + 64 * (k0 + kk);
-                const unsigned o = TapO[pix];
-                w[kk] = TapW[pix];
-                const float *a = img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
-                const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? row_off : 0u;
-                v[kk][0] = *reinterpret_cast<const f32x4 *>(a);
-                v[kk][1] = *reinterpret_cast<const f32x4 *>(a + dxo);
-                v[kk][2] = *reinterpret_cast<const f32x4 *>(a + dyo);
-                v[kk][3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
-            }
-#pragma unroll
-            for (int kk = 0; kk < 3; ++kk) {
-                const int pix = pl + 64 * (k0 + kk);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc += v[kk][0] * (w[kk][0] * w[kk][2]);      // same order as warp_mvq_nhwc_kernel
-                acc += v[kk][1] * (w[kk][1] * w[kk][2]);
-                acc += v[kk][2] * (w[kk][0] * w[kk][3]);
-                acc += v[kk][3] * (w[kk][1] * w[kk][3]);
-                BIGf[g16 * HPL + pix] = acc;
-            }
+        const int lane = tid0 & 63, q = lane & 15, g = lane >> 4, qy = q >> 3, qx = q & 7;
+        for (int s = 0; s < 28; ++s) {
+            const int f = 16 * (s >> 2) + 4 * g + (s & 3), ky = f / 14, kx = f - 14 * ky;
+            if ((unsigned)(ky - qy) <= 6u && (unsigned)(kx - qx) <= 6u) okmask |= 1u << s;
         }
     }
-    __syncthreads();
+  for (int tile = t_lo + slot; tile < t_hi; tile += nslot) {
+    // Everything derived from the thread id is recomputed per phase from an opaque copy: left alone, LLVM hoists the per-lane
+    // constants of all phases (record indices, masks, addresses) to the top of the tile loop where they occupy ~100 registers.
+#define RR_TID(t) int t = tid0; asm volatile("" : "+v"(t))
+#ifdef RR_TIMING
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
+    const int n = tile / per_img, trem = tile - n * per_img;
+    const int ty0 = (trem / p.tiles_x) * TY, tx0 = (trem - (trem / p.tiles_x) * p.tiles_x) * TX;
+    const int Hp = p.Hp, Wp = p.Wp;
 
-    // ------------------------------------------------------------------ phase 2: walker columns into registers
-    // lane = DPP row r4 (span = r4 & 1, half = r4 >> 1) x 16 columns; channel group = wave
-    const int r4 = lane >> 4, xi = lane & 15;
-    const int xr = 8 * (r4 & 1) + xi;                          // region column of this lane
-    const int rb = 11 * (r4 >> 1);                             // first region row of its 13-row column
-    f32x4 h[13];
-#pragma unroll
-    for (int j = 0; j < 13; ++j) h[j] = BIGf[wave * HPL + (rb + j) * R4W + xr];
-    // record column / validity of this lane's conv outputs: span 0 writes record columns 0..10, span 1 columns 11..21
-    const int xk = xr - 1;
-    const bool wr_ok = (r4 & 1) ? (xi >= 4 && xi <= 14) : (xi >= 1 && xi <= 11);
-    const bool col_in = (unsigned)(tx0 - 3 + xk) < (unsigned)Wp;
-    __syncthreads();
-
-    // ------------------------------------------------------------------ phase 3: lr_up tile (+1 halo), all 64 channels
+    // ------------------------------------------------------------------ phase 0: lr_up tile (+1 halo, all 64 channels) into LDS; sampling taps
+    // The tap arithmetic (fp64, one lane per region pixel) runs while the first batch of lr loads is in flight.
     {
+        RR_TID(t);
         const float *lrn = p.lr + (size_t)n * p.hp * p.wp * CH;
-        const int g16 = tid & 15, pl = tid >> 4;
-#pragma unroll 1
-        for (int k0 = 0; k0 < 6; k0 += 2) {
-            f32x4 v[2][4]; f32x4 tyv[2], txv[2];
+        const int g16 = t & 15, pl = t >> 4;
+        auto lr_issue = [&](int k, f32x4 (&v)[4], float &ly, float &lx, bool &inside) {
+            const int px = min(pl + 64 * k, LN - 1);
+            const int r = px / LW, c = px - r * LW;
+            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
+            int y0, y1, x0, x1;
+            arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, y0, y1, ly);
+            arseg_src_index(p.sx, min(max(gx, 0), Wp - 1), true, p.wp, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+            inside = (unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp;
+            const float *b = lrn + g16 * 4;
+            v[0] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y0 * p.wp + x0) * CH);
+            v[1] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y0 * p.wp + x1) * CH);
+            v[2] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y1 * p.wp + x0) * CH);
+            v[3] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y1 * p.wp + x1) * CH);
+        };
+        auto lr_commit = [&](int k, const f32x4 (&v)[4], float ly, float lx, bool inside) {
+            const int px = pl + 64 * k;
+            f32x4 o = (1.f - ly) * ((1.f - lx) * v[0] + lx * v[1]) + ly * ((1.f - lx) * v[2] + lx * v[3]);
+            if (!inside) o = f32x4{0.f, 0.f, 0.f, 0.f};           // conv zero padding outside the image
+            if (px < LN) BIGf[g16 * LPL + px] = o;
+        };
+        f32x4 va[3][4]; float lya[3], lxa[3]; bool ina[3];
+        if (RR_ON(2)) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int px = min(pl + 64 * (k0 + kk), LN - 1);
-                const int r = px / LW, c = px - r * LW;
-                tyv[kk] = Tb[r]; txv[kk] = Tb[LW + c];
-                const int r0 = __float_as_int(tyv[kk][0]), r1 = __float_as_int(tyv[kk][1]), x0 = __float_as_int(txv[kk][0]), x1 = __float_as_int(txv[kk][1]);
-                const float *b = lrn + g16 * 4;
-                v[kk][0] = *reinterpret_cast<const f32x4 *>(b + (size_t)(r0 + x0) * CH);
-                v[kk][1] = *reinterpret_cast<const f32x4 *>(b + (size_t)(r0 + x1) * CH);
-                v[kk][2] = *reinterpret_cast<const f32x4 *>(b + (size_t)(r1 + x0) * CH);
-                v[kk][3] = *reinterpret_cast<const f32x4 *>(b + (size_t)(r1 + x1) * CH);
+            for (int k = 0; k < 3; ++k) lr_issue(k, va[k], lya[k], lxa[k], ina[k]);
+        }
+        if (!RR_ON(0)) {
+            if (t < R4N) { TapW[t] = f32x4{0.5f, 0.5f, 0.5f, 0.5f}; TapO[t] = (unsigned)t; }
+        } else if (t < R4N) {
+            const int yr = t / R4W, xr = t - yr * R4W;
+            const int gy = ty0 - 4 + yr, gx = tx0 - 4 + xr;
+            f32x4 w = {0.f, 0.f, 0.f, 0.f};
+            unsigned o = 0;
+            if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp) {      // outside the image the region is zero (conv padding)
+                double fx, fy;
+                const int16_t *mvn = p.mv + (size_t)n * p.H * p.W * 2;
+                if (Hp == p.H && Wp == p.W) {          // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
+                    const int16_t *m = mvn + ((size_t)gy * p.W + gx) * 2;
+                    fx = (double)m[0] / 4.0; fy = (double)m[1] / 4.0;
+                } else {
+                    mv_at(mvn, p.H, p.W, Hp, Wp, gy, gx, fx, fy);
+                }
+                float ngx, ngy;
+                norm_grid<double>(gx, gy, fx, fy, Hp, Wp, ngx, ngy);
+                const Taps tp = make_taps(ngx, ngy, Hp, Wp);
+                const int xa = min(max(tp.x0, 0), Wp - 1), xc = min(max(tp.x0 + 1, 0), Wp - 1);
+                const int ya = min(max(tp.y0, 0), Hp - 1), yc = min(max(tp.y0 + 1, 0), Hp - 1);
+                o = (unsigned)(ya * Wp + xa) | ((unsigned)(xc - xa) << 30) | ((unsigned)(yc - ya) << 31);
+                w = f32x4{tp.vx0 ? tp.ex : 0.f, tp.vx1 ? tp.wx : 0.f, tp.vy0 ? tp.ey : 0.f, tp.vy1 ? tp.wy : 0.f};
             }
+            TapW[t] = w; TapO[t] = o;
+        }
+        if (RR_ON(2)) {
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int px = pl + 64 * (k0 + kk);
-                const float ly = tyv[kk][2], lx = txv[kk][2];
-                f32x4 o = (1.f - ly) * ((1.f - lx) * v[kk][0] + lx * v[kk][1]) + ly * ((1.f - lx) * v[kk][2] + lx * v[kk][3]);
-                if (tyv[kk][3] * txv[kk][3] == 0.f) o = f32x4{0.f, 0.f, 0.f, 0.f};      // conv zero padding outside the image
-                if (px < LN) BIGf[g16 * LPL + px] = o;
-            }
+            for (int k = 0; k < 3; ++k) lr_commit(k, va[k], lya[k], lxa[k], ina[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lr_issue(3 + k, va[k], lya[k], lxa[k], ina[k]);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lr_commit(3 + k, va[k], lya[k], lxa[k], ina[k]);
         }
     }
     __syncthreads();
+    RR_STAMP(1);
 
-    // ------------------------------------------------------------------ phase 4: query conv, lane local (channels 16c + 4g .. +3 of the lane's own query)
+    // ------------------------------------------------------------------ phase 1: query conv, lane local (channels 16c + 4g .. +3 of the lane's own query)
     u32x2 qh[4], ql[4];
+    {
+        RR_TID(t);
+        const int lane = t & 63, wave = t >> 6, q = lane & 15, g = lane >> 4;
+        const int yq = 2 * (wave >> 1) + (q >> 3), xq = 8 * (wave & 1) + (q & 7);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const f32x4 *w = WdQ + c * 40;
-        const f32x4 *ls = BIGf + (4 * c + g) * LPL + yq * LW + xq;
-        f32x4 qv = w[9 * 4 + g];
+        for (int c = 0; c < 4; ++c) { qh[c] = u32x2{(unsigned)t, 0u}; ql[c] = qh[c]; }
+        if (RR_ON(3))
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 *w = WdQ + c * 40;
+            const f32x4 *ls = BIGf + (4 * c + g) * LPL + yq * LW + xq;
+            f32x4 qv = w[9 * 4 + g];
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) qv = fma4(w[(dy * 3 + dx) * 4 + g], ls[dy * LW + dx], qv);
-        split4(qv, qh[c], ql[c]);
-        // pin the result here: LLVM otherwise sinks the whole FMA chain to its use in phase 6 and keeps the 76 loaded vectors alive
-        asm volatile("" : "+v"(qh[c].x), "+v"(qh[c].y), "+v"(ql[c].x), "+v"(ql[c].y));
-        __builtin_amdgcn_sched_barrier(0);      // one chunk at a time: hoisting all 36 tile reads would spill the walker columns
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) qv = fma4(w[(dy * 3 + dx) * 4 + g], ls[dy * LW + dx], qv);
+            split4(qv, qh[c], ql[c]);
+            // pin the result here: LLVM otherwise sinks the whole FMA chain to its use in the score phase and keeps the 76 loaded vectors alive
+            asm volatile("" : "+v"(qh[c].x), "+v"(qh[c].y), "+v"(ql[c].x), "+v"(ql[c].y));
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     __syncthreads();
+    RR_STAMP(2);
 
-    // ------------------------------------------------------------------ phases 5 / 7: key (value) records of the whole region
+    // ------------------------------------------------------------------ phase 2: gather + bilinear warp of the region into LDS
+    // unit = (region pixel, channel group): 16 lanes read one whole 256-byte pixel per tap
+    if (RR_ON(1)) {
+        RR_TID(t);
+        const float *img = p.ref[n];
+        const int g16 = t & 15, pl = t >> 4;
+        const unsigned row_off = (unsigned)Wp * CH;
+        auto issue = [&](int k, f32x4 (&v)[4], f32x4 &w) {
+            const int pix = pl + 64 * k;
+            const unsigned o = TapO[pix];
+            w = TapW[pix];
+            const float *a = img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
+            const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? row_off : 0u;
+            v[0] = *reinterpret_cast<const f32x4 *>(a);
+            v[1] = *reinterpret_cast<const f32x4 *>(a + dxo);
+            v[2] = *reinterpret_cast<const f32x4 *>(a + dyo);
+            v[3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
+        };
+        auto commit = [&](int k, const f32x4 (&v)[4], const f32x4 w) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc += v[0] * (w[0] * w[2]);      // same order as warp_mvq_nhwc_kernel
+            acc += v[1] * (w[1] * w[2]);
+            acc += v[2] * (w[0] * w[3]);
+            acc += v[3] * (w[1] * w[3]);
+            BIGf[g16 * HPL + pl + 64 * k] = acc;
+        };
+        f32x4 v[5][4], w[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) issue(k, v[k], w[k]);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) commit(k, v[k], w[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) issue(5 + k, v[k], w[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) commit(5 + k, v[k], w[k]);
+    }
+    __syncthreads();
+    RR_STAMP(3);
+
+    // ------------------------------------------------------------------ phase 3: walker columns into registers
+    // lane = DPP row r4 (span = r4 & 1, half = r4 >> 1) x 16 columns; channel group = wave
+    f32x4 h[13];
+    {
+        RR_TID(t);
+        const int lane = t & 63, wave = t >> 6, r4 = lane >> 4, xi = lane & 15;
+        const int xr = 8 * (r4 & 1) + xi, rb = 11 * (r4 >> 1);
+#pragma unroll
+        for (int j = 0; j < 13; ++j) h[j] = BIGf[wave * HPL + (RR_ON(2) ? (rb + j) * R4W + xr : 0)];
+    }
+    __syncthreads();
+    RR_STAMP(4);
+
+    // ------------------------------------------------------------------ phases 4 / 6: key (value) records of the whole region
     auto conv_records = [&](const float *wt, const float *bs, int kpl) {
+        RR_TID(t);
+        const int lane = t & 63, r4 = lane >> 4, xi = lane & 15;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+        const int xk = 8 * (r4 & 1) + xi - 1, rb = 11 * (r4 >> 1);       // record column, first record row of this lane
+        // span 0 writes record columns 0..10, span 1 columns 11..21
+        const bool wr_ok = (r4 & 1) ? (xi >= 4 && xi <= 14) : (xi >= 1 && xi <= 11);
+        const bool col_in = (unsigned)(tx0 - 3 + xk) < (unsigned)Wp;
         // wave-uniform weights in scalar registers.  Issued through asm: behind the barriers hipcc no longer proves the weight
         // memory unclobbered and would fetch the 40 values into VGPRs with vector loads.
         const float *wg = wt + 4 * wave, *bg = bs + 4 * wave;
@@ -281,11 +325,12 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                      : "s"(wg), "s"(bg) : "memory");
         f32x4 w[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = __builtin_bit_cast(f32x4, ws[t]);
+        for (int tp = 0; tp < 9; ++tp) w[tp] = __builtin_bit_cast(f32x4, ws[tp]);
         const f32x4 bias = __builtin_bit_cast(f32x4, bsv);
         f32x4 l0 = dpp4<0x111>(h[0]), r0 = dpp4<0x101>(h[0]);
         f32x4 l1 = dpp4<0x111>(h[1]), r1 = dpp4<0x101>(h[1]);
-        u32x4 *dst = BIGu + wave * kpl + xk;
+        u32x4 *dst = BIGu + wave * kpl + rb * R3W + xk;
+        int gy = ty0 - 3 + rb;
 #pragma unroll
         for (int j = 0; j < 11; ++j) {
             const f32x4 l2 = dpp4<0x111>(h[j + 2]), r2 = dpp4<0x101>(h[j + 2]);
@@ -293,52 +338,52 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             acc = fma4(w[0], l0, acc); acc = fma4(w[1], h[j], acc); acc = fma4(w[2], r0, acc);
             acc = fma4(w[3], l1, acc); acc = fma4(w[4], h[j + 1], acc); acc = fma4(w[5], r1, acc);
             acc = fma4(w[6], l2, acc); acc = fma4(w[7], h[j + 2], acc); acc = fma4(w[8], r2, acc);
-            const int yk = rb + j;
-            const bool in = col_in && (unsigned)(ty0 - 3 + yk) < (unsigned)Hp;
-            if (!in) acc = f32x4{0.f, 0.f, 0.f, 0.f};         // the unfold's zero padding
+            // the unfold's zero padding, as a mask on the packed record (a select on acc makes hipcc branch around the FMAs)
+            const unsigned in = (col_in && (unsigned)(gy + j) < (unsigned)Hp) ? 0xFFFFFFFFu : 0u;
             u32x2 hi, lo;
             split4(acc, hi, lo);
-            if (wr_ok) dst[yk * R3W] = u32x4{hi.x, hi.y, lo.x, lo.y};
+            if (wr_ok) dst[j * R3W] = u32x4{hi.x & in, hi.y & in, lo.x & in, lo.y & in};
             l0 = l1; r0 = r1; l1 = l2; r1 = r2;
             __builtin_amdgcn_sched_barrier(0);      // row by row: hoisting the neighbour moves of all 13 rows would spill the columns
         }
     };
-    conv_records(p.wk, p.bk, KPLK);
+    if (RR_ON(4)) conv_records(p.wk, p.bk, KPLK);
     __syncthreads();
+    RR_STAMP(5);
 
-    // ------------------------------------------------------------------ phase 6: scores S[b][i] = q . key(16b + 4g + i), then softmax
-    f32x4 S[7];
-#pragma unroll
-    for (int b = 0; b < 7; ++b) S[b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    {
-        int krec[7];
-#pragma unroll
-        for (int b = 0; b < 7; ++b) krec[b] = key_rec(16 * b + q, pc, pr);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const u32x4 *ka = BIGu + (4 * c + g) * KPLK;
-            const h16x8 b1 = pack8(qh[c], ql[c]), b2 = pack8(ql[c], qh[c]);
-#pragma unroll
-            for (int b = 0; b < 7; ++b) {
-                const h16x8 a = __builtin_bit_cast(h16x8, ka[krec[b]]);
-                S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, S[b], 0, 0, 0);
-                S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, S[b], 0, 0, 0);
-            }
-        }
-    }
-    // softmax over the 49 taps (padding taps included); slot (b, i) is key f = 16b + 4g + i = (ky, kx): real iff both
-    // ky - qy and kx - qx lie in [0, 6]
+    // ------------------------------------------------------------------ phase 5: scores S[b][i] = q . key(16b + 4g + i), then softmax
     float inv;
     u32x4 P[7];
     {
+        RR_TID(t);
+        const int lane = t & 63, q = lane & 15, g = lane >> 4;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), pc = wave & 1, pr = wave >> 1;
+        f32x4 S[7];
+#pragma unroll
+        for (int b = 0; b < 7; ++b) S[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (RR_ON(5)) {
+            int krec[7];
+#pragma unroll
+            for (int b = 0; b < 7; ++b) krec[b] = key_rec(b, q, 2 * pr * R3W + 8 * pc + q);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const u32x4 *ka = BIGu + (4 * c + g) * KPLK;
+                const h16x8 b1 = pack8(qh[c], ql[c]), b2 = pack8(ql[c], qh[c]);
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const h16x8 a = __builtin_bit_cast(h16x8, ka[krec[b]]);
+                    S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, S[b], 0, 0, 0);
+                    S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, S[b], 0, 0, 0);
+                }
+            }
+        }
+            // softmax over the 49 taps (padding taps included)
         float m = -INFINITY;
 #pragma unroll
         for (int b = 0; b < 7; ++b)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const int f = 16 * b + 4 * g + i, ky = (f * 147) >> 11, kx = f - 14 * ky;
-                const bool ok = (unsigned)(ky - qy) <= 6u && (unsigned)(kx - qx) <= 6u;
-                S[b][i] = ok ? S[b][i] : -INFINITY;
+                S[b][i] = (okmask >> (4 * b + i)) & 1u ? S[b][i] : -INFINITY;
                 m = fmaxf(m, S[b][i]);
             }
         m = fmaxf(m, __shfl_xor(m, 16));
@@ -359,120 +404,156 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         z += __shfl_xor(z, 16);
         z += __shfl_xor(z, 32);
         inv = 1.0f / z;                            // applied to the weighted sum instead of the 112 weights
-    }
-    __syncthreads();
-
-    // ------------------------------------------------------------------ phase 7: value records (the key records are dead)
-    conv_records(p.wv, p.bv, KPLV);
-    // classifier records [chunk][group][class] {4 hi | 4 lo} into the (dead) tap tables
-    if (NB > 0 && tid < 4 * 4 * NBA * 16) {
-        const int cls = tid % (NBA * 16), gg = (tid / (NBA * 16)) & 3, c = tid / (4 * NBA * 16);
-        f32x4 wv4 = {0.f, 0.f, 0.f, 0.f};
-        if (cls < p.n_cls) wv4 = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)cls * CH + c * 16 + gg * 4);
-        u32x2 hi, lo;
-        split4(wv4, hi, lo);
-        Wfs[tid] = __builtin_bit_cast(f32x4, u32x4{hi.x, hi.y, lo.x, lo.y});
-    }
-    __syncthreads();
-
-    // ------------------------------------------------------------------ phase 8: P.V, residual, classifier, stores
-    f32x4 lg[NBA];
 #pragma unroll
-    for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool inq = gyq < Hp && gxq < Wp;
-    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
+        for (int b = 0; b < 7; ++b) asm volatile("" : "+v"(P[b]));      // finish the softmax here, not behind the value conv
+    }
+    __syncthreads();
+    RR_STAMP(6);
+
+    // ------------------------------------------------------------------ phase 6: value records (the key records are dead)
+    if (RR_ON(6)) conv_records(p.wv, p.bv, KPLV);
+    // classifier records [chunk][group][class] {4 hi | 4 lo}, behind the value records
     {
-        // residual term lr_up(own pixel): bilinear taps (table rows clamp into the image)
-        const f32x4 tyv = Tb[yq + 1], txv = Tb[LW + xq + 1];
-        const int r0 = __float_as_int(tyv[0]), r1 = __float_as_int(tyv[1]), x0 = __float_as_int(txv[0]), x1 = __float_as_int(txv[1]);
-        const float ly = tyv[2], lx = txv[2];
-        const float *lrn = p.lr + (size_t)n * p.hp * p.wp * CH + 4 * g;
-        int vrec[7];
+        RR_TID(t);
+        if (NB > 0 && t < 4 * 4 * NBA * 16) {
+            const int cls = t % (NBA * 16), gg = (t / (NBA * 16)) & 3, c = t / (4 * NBA * 16);
+            f32x4 wv4 = {0.f, 0.f, 0.f, 0.f};
+            if (cls < p.n_cls) wv4 = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)cls * CH + c * 16 + gg * 4);
+            u32x2 hi, lo;
+            split4(wv4, hi, lo);
+            Wfs[t] = __builtin_bit_cast(f32x4, u32x4{hi.x, hi.y, lo.x, lo.y});
+        }
+    }
+    __syncthreads();
+    RR_STAMP(7);
+
+    // ------------------------------------------------------------------ phase 7: P.V, residual, classifier, stores
+    {
+        RR_TID(t);
+        const int lane = t & 63, q = lane & 15, g = lane >> 4;
+        const int wave = __builtin_amdgcn_readfirstlane(t >> 6), pc = wave & 1, pr = wave >> 1;
+        const int gyq = ty0 + 2 * pr + (q >> 3), gxq = tx0 + 8 * pc + (q & 7);       // this lane's query pixel
+        const bool inq = gyq < Hp && gxq < Wp;
+        f32x4 lg[NBA];
 #pragma unroll
-        for (int b = 0; b < 7; ++b) vrec[b] = key_rec(16 * b + 4 * g + (q >> 2), pc, pr);
+        for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
+        if (RR_ON(7)) {
+            // residual term lr_up(own pixel): bilinear(align_corners=True) taps, coordinates clamped into the image
+            int y0, y1, x0, x1; float ly, lx;
+            arseg_src_index(p.sy, min(gyq, Hp - 1), true, p.hp, y0, y1, ly);
+            arseg_src_index(p.sx, min(gxq, Wp - 1), true, p.wp, x0, x1, lx);
+            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
+            const float *lrn = p.lr + (size_t)n * p.hp * p.wp * CH + 4 * g;
+            const float *a00p = lrn + (size_t)(y0 * p.wp + x0) * CH, *a01p = lrn + (size_t)(y0 * p.wp + x1) * CH;
+            const float *a10p = lrn + (size_t)(y1 * p.wp + x0) * CH, *a11p = lrn + (size_t)(y1 * p.wp + x1) * CH;
+            int vrec[7];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float *b0 = lrn + 16 * c;
-            const f32x4 a00 = *reinterpret_cast<const f32x4 *>(b0 + (size_t)(r0 + x0) * CH), a01 = *reinterpret_cast<const f32x4 *>(b0 + (size_t)(r0 + x1) * CH);
-            const f32x4 a10 = *reinterpret_cast<const f32x4 *>(b0 + (size_t)(r1 + x0) * CH), a11 = *reinterpret_cast<const f32x4 *>(b0 + (size_t)(r1 + x1) * CH);
-            const unsigned char *va = reinterpret_cast<const unsigned char *>(BIGu + (4 * c + (q & 3)) * KPLV);
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < 7; ++b) vrec[b] = key_rec(b, 4 * g + (q >> 2), 2 * pr * R3W + 8 * pc + 4 * g + (q >> 2)) * 16;
+            // the four taps of a chunk are requested one chunk ahead: their latency hides behind the 14 MFMAs of the current one
+            f32x4 a00 = *reinterpret_cast<const f32x4 *>(a00p), a01 = *reinterpret_cast<const f32x4 *>(a01p);
+            f32x4 a10 = *reinterpret_cast<const f32x4 *>(a10p), a11 = *reinterpret_cast<const f32x4 *>(a11p);
 #pragma unroll
-            for (int b = 0; b < 7; ++b) {
-                const u32x2 vh = lds_tr16(va + vrec[b] * 16), vl = lds_tr16(va + vrec[b] * 16 + 8);
-                const h16x8 pb = __builtin_bit_cast(h16x8, P[b]);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
-            }
-            const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
-            const f32x4 o = lrc + acc * inv;              // p[query][16c + 4g .. +3]
-            unsigned off;
-            if (p.p_layout == ARSEG_C8)
-                off = (unsigned)(((((size_t)n * 8 + 2 * c + (g >> 1)) * Hp + gyq) * Wp + gxq) * 8 + (g & 1) * 4) * 4u;
-            else
-                off = (unsigned)((((size_t)n * Hp + gyq) * Wp + gxq) * CH + 16 * c + 4 * g) * 4u;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? off : OOB, 0, 0);
-            if (NB > 0) {
-                u32x2 oh, ol;
-                split4(o, oh, ol);
-                const h16x8 o1 = pack8(oh, ol), o2 = pack8(ol, oh);
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
+                if (c < 3) {
+                    a00 = *reinterpret_cast<const f32x4 *>(a00p + 16 * (c + 1)); a01 = *reinterpret_cast<const f32x4 *>(a01p + 16 * (c + 1));
+                    a10 = *reinterpret_cast<const f32x4 *>(a10p + 16 * (c + 1)); a11 = *reinterpret_cast<const f32x4 *>(a11p + 16 * (c + 1));
+                }
+                const unsigned char *va = reinterpret_cast<const unsigned char *>(BIGu + (4 * c + (q & 3)) * KPLV);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int nb = 0; nb < NBA; ++nb) {
-                    const h16x8 wa = __builtin_bit_cast(h16x8, Wfs[(c * 4 + g) * NBA * 16 + nb * 16 + q]);
-                    lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o1, lg[nb], 0, 0, 0);
-                    lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o2, lg[nb], 0, 0, 0);
+                for (int b = 0; b < 7; ++b) {
+                    const u32x2 vh = lds_tr16(va + vrec[b]), vl = lds_tr16(va + vrec[b] + 8);
+                    const h16x8 pb = __builtin_bit_cast(h16x8, P[b]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
+                }
+                const f32x4 o = lrc + acc * inv;              // p[query][16c + 4g .. +3]
+                unsigned off;
+                if (p.p_layout == ARSEG_C8)
+                    off = (unsigned)(((((size_t)n * 8 + 2 * c + (g >> 1)) * Hp + gyq) * Wp + gxq) * 8 + (g & 1) * 4) * 4u;
+                else
+                    off = (unsigned)((((size_t)n * Hp + gyq) * Wp + gxq) * CH + 16 * c + 4 * g) * 4u;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? off : OOB, 0, 0);
+                if (NB > 0) {
+                    u32x2 oh, ol;
+                    split4(o, oh, ol);
+                    const h16x8 o1 = pack8(oh, ol), o2 = pack8(ol, oh);
+#pragma unroll
+                    for (int nb = 0; nb < NBA; ++nb) {
+                        const h16x8 wa = __builtin_bit_cast(h16x8, Wfs[(c * 4 + g) * NBA * 16 + nb * 16 + q]);
+                        lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o1, lg[nb], 0, 0, 0);
+                        lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o2, lg[nb], 0, 0, 0);
+                    }
                 }
             }
         }
-    }
 
-    // ------------------------------------------------------------------ logits: lg[nb][i] = class 16nb + 4g + i of query q
-    if (NB > 0) {
-        const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
-        float m = -INFINITY;
-#pragma unroll
-        for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cls = nb * 16 + 4 * g + i;
-                lg[nb][i] += p.bf[min(cls, p.n_cls - 1)];
-                m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
-            }
-        if (p.log_softmax) {
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
-            float z = 0.f;
+        // logits: lg[nb][i] = class 16nb + 4g + i of query q
+        if (NB > 0) {
+            const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
+            float m = -INFINITY;
 #pragma unroll
             for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? expf(lg[nb][i] - m) : 0.f;
-            z += __shfl_xor(z, 16);
-            z += __shfl_xor(z, 32);
-            const float lse = m + logf(z);
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = nb * 16 + 4 * g + i;
+                    lg[nb][i] += p.bf[min(cls, p.n_cls - 1)];
+                    m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
+                }
+            if (p.log_softmax) {
+                m = fmaxf(m, __shfl_xor(m, 16));
+                m = fmaxf(m, __shfl_xor(m, 32));
+                float z = 0.f;
 #pragma unroll
-            for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
-        }
+                for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-        for (int nb = 0; nb < NBA; ++nb)
+                    for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? __expf(lg[nb][i] - m) : 0.f;
+                z += __shfl_xor(z, 16);
+                z += __shfl_xor(z, 32);
+                const float lse = m + __logf(z);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int cls = nb * 16 + 4 * g + i;
-                const unsigned off = (unsigned)(((((size_t)n * p.n_cls + cls) * Hp + gyq) * Wp + gxq) * sizeof(float));
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB, 0, 0);
+                for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
             }
+#pragma unroll
+            for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int cls = nb * 16 + 4 * g + i;
+                    const unsigned off = (unsigned)(((((size_t)n * p.n_cls + cls) * Hp + gyq) * Wp + gxq) * sizeof(float));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB, 0, 0);
+                }
+        }
     }
+    __syncthreads();          // the next tile's tables / staging overwrite LDS this tile still reads
+    RR_STAMP(8);
+#ifdef RR_TIMING
+    if (tid0 == 0 && p.dbg) atomicAdd(p.dbg + 15, 1ull);
+#endif
+  }
 }
 
 template <int NB>
 int launch(const RRParams &p, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_rr_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
     if (e != hipSuccess) return (int)e;
-    dim3 grid(arseg_cdiv(p.Wp, TX), arseg_cdiv(p.Hp, TY), p.N);
-    hipLaunchKernelGGL((creff_rr_kernel<NB>), grid, dim3(NT), SMEM_BYTES, st, p);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const long long ntiles = (long long)p.tiles_x * p.tiles_y * p.N;
+    const int grid = (int)(ntiles < cus ? ntiles : cus);
+    hipLaunchKernelGGL((creff_rr_kernel<NB>), dim3(grid), dim3(NT), SMEM_BYTES, st, p);
     return arseg_launch_status();
 }
 
+#ifdef RR_TIMING
+unsigned long long *g_rr_dbg = nullptr;
+#endif
 }  // namespace
+
+#ifdef RR_TIMING
+extern "C" void arseg__rr_set_dbg(void *ptr) { g_rr_dbg = (unsigned long long *)ptr; }
+#endif
 
 extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
                                     const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
@@ -505,9 +586,13 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
     p.mv = mv_q; p.lr = lr; p.wq = wq; p.bq = bq; p.wk = wk; p.bk = bk; p.wv = wv; p.bv = bv; p.wf = wf; p.bf = bf;
     p.p_out = p_out; p.logits = logits;
     p.N = N; p.Hp = Hp; p.Wp = Wp; p.hp = hp; p.wp = wp; p.H = H; p.W = W; p.n_cls = head ? n_cls : 0; p.log_softmax = log_softmax;
-    p.p_layout = p_layout;
+    p.p_layout = p_layout; p.tiles_x = arseg_cdiv(Wp, TX); p.tiles_y = arseg_cdiv(Hp, TY);
     p.p_bytes = (unsigned)((size_t)N * C * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)N * n_cls * Hp * Wp * sizeof(float)) : 0u;
     p.sy = arseg_resize_scale(hp, Hp, true); p.sx = arseg_resize_scale(wp, Wp, true);
+    p.dbg = nullptr;
+#ifdef RR_TIMING
+    p.dbg = g_rr_dbg;
+#endif
     hipStream_t st = arseg_stream(stream);
     if (!head) return launch<0>(p, st);
     return n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);

@@ -6,7 +6,7 @@
   (``dl`` is any iterable of the reference's sample tuples).  Networks may be bare modules or
   wrapped in ``nn.DataParallel`` (the reference addresses ``net.module`` on the hot path).
 * ``alter_res_step_fast`` -- the same non-keyframe step on the kernel-native layouts (int16 MVs in,
-  fused MV-resize + warp writing C8, fused CReFF + head), used by the GOP runner and bench.py.
+  MV resize + warp + CReFF + head fused), used by the GOP runner and bench.py.
 
 The CLI / dataset walking of the reference (evaluation.py:218-439) needs the datasets and
 checkpoints and is out of scope.
@@ -131,9 +131,8 @@ def alter_res_step_fast(lr_net, ref_p_nhwc, img, mv_q, scale=0.5):
     lr_net = _unwrap(lr_net)
     N, C, H, W = img.shape
     h, w = _downscale_hw(H, W, scale)
-    ref_c8 = ops.warp_mvq(ref_p_nhwc, mv_q, _lib.C8)                  # a2 + a1
     feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(img, h, w))[-1]     # a3 + phase 1
-    return lr_net.phase2_c8(feat, ref_c8)                             # CReFF + head
+    return lr_net.phase2_warp(feat, [ref_p_nhwc[i] for i in range(N)], mv_q)      # a2 + a1 + CReFF + head
 
 
 def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
@@ -150,9 +149,5 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
         outs = [alter_res_batch_fast(lr_net, ref_ps[i:i + sub], imgs[i:i + sub], mv_qs[i:i + sub], scale) for i in range(0, B, sub)]
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     h, w = _downscale_hw(H, W, scale)
-    Hp, Wp, C = ref_ps[0].shape
-    ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=imgs.device)
-    for b in range(B):                                                 # a2 + a1 per frame (each has its own MV map)
-        ops.warp_mvq(ref_ps[b].unsqueeze(0), mv_qs[b:b + 1], _lib.C8, out=ref_c8[b:b + 1])
     feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(imgs, h, w))[-1]     # a3 + phase 1, batched
-    return lr_net.phase2_c8(feat, ref_c8)                              # CReFF + head, batched
+    return lr_net.phase2_warp(feat, list(ref_ps), mv_qs)               # a2 + a1 (each frame has its own MV map) + CReFF + head

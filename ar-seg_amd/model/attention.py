@@ -70,17 +70,14 @@ class MyAttention(HipModule):
         """Kernel-layout entry: warped HR feature in C8, LR feature NHWC -> (p C8, logits NCHW | None)."""
         return ops.creff(hr_c8, lr_nhwc, self.packed(), head, log_softmax, self.kH, self.kW)
 
+    def fuse_warp(self, refs_nhwc, mv_q, lr_nhwc, head=None, log_softmax=False):
+        """warpFeature + forward (+ head) on the kernel layouts: un-warped keyframe features NHWC [Hp,Wp,C] (one per frame),
+        int16 quarter-pel MVs [B,H,W,2], LR feature NHWC -> (p C8, logits NCHW | None).  One kernel for C == 64
+        (arseg_creff_warp_fwd); arseg_warp_mvq_fwd + arseg_creff_fwd otherwise."""
+        return ops.creff_warp(refs_nhwc, mv_q, lr_nhwc, self.packed(), head, log_softmax, self.kH, self.kW)
+
     def forward(self, hr_feat, lr_feat):
         """hr_feat [N,C,H,W], lr_feat [N,C,h,w] (logical NCHW, any strides) -> [N,C,H,W]."""
         hr_c8 = ops.to_c8(ops.to_nhwc(hr_feat), _lib.NHWC) if ops.is_nhwc_view(hr_feat) else ops.to_c8(hr_feat, _lib.NCHW)
         p_c8, _ = self.fuse_c8(hr_c8, ops.to_nhwc(lr_feat))
         return ops.as_nchw(ops.from_c8(p_c8, _lib.NHWC))
-
-    def get_params(self):
-        wd_params, nowd_params = [], []
-        for _, module in self.named_modules():
-            if isinstance(module, (nn.Linear, nn.Conv2d)):
-                wd_params.append(module.weight)
-                if module.bias is not None:
-                    nowd_params.append(module.bias)
-        return wd_params, nowd_params

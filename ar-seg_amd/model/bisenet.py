@@ -349,6 +349,13 @@ class BiSeNetV1WithFuse(_BiSeBase):
         N, n_cls, h, w = lo.shape
         return ops.resize_nchw(lo, 8 * h, 8 * w, _lib.BILINEAR, False), p_c8                   # out_upsample
 
+    def phase2_warp(self, mid_nhwc, refs_nhwc, mv_q):
+        """Phase 2 with the MV warp in front (fast path): -> (logits NCHW at full resolution, p C8)."""
+        hd = self.conv_out.packed()
+        p_c8, lo = self.fuse_attention.fuse_warp(refs_nhwc, mv_q, mid_nhwc, head=(hd.wf, hd.bf), log_softmax=False)
+        N, n_cls, h, w = lo.shape
+        return ops.resize_nchw(lo, 8 * h, 8 * w, _lib.BILINEAR, False), p_c8                   # out_upsample
+
     def forward_phase2(self, middle_feat, ref_p):
         self._check_inference()
         ref_c8 = ops.to_c8(ops.to_nhwc(ref_p), _lib.NHWC) if ops.is_nhwc_view(ref_p) else ops.to_c8(ref_p, _lib.NCHW)

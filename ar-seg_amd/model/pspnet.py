@@ -177,6 +177,13 @@ class PSPNetWithFuse(_PSPBase):
         p_c8, out = self.fuse_attention.fuse_c8(ref_c8, p_nhwc, head=(hd.wf, hd.bf), log_softmax=True)
         return out, p_c8
 
+    def phase2_warp(self, p_nhwc, refs_nhwc, mv_q):
+        """Phase 2 with the MV warp fused in (fast path): LR feature NHWC, un-warped keyframe features NHWC [Hp,Wp,C] (one per
+        frame), int16 MVs -> (log-probs NCHW, p C8)."""
+        hd = self.packed()["head"]
+        p_c8, out = self.fuse_attention.fuse_warp(refs_nhwc, mv_q, p_nhwc, head=(hd.wf, hd.bf), log_softmax=True)
+        return out, p_c8
+
     def forward_phase2(self, p, ref_p):
         self._check_inference()
         N, C, H, W = ref_p.shape

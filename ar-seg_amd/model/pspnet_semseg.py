@@ -172,6 +172,12 @@ class PSPNetWithFuse(_SemsegBase):
         p_c8, out = self.fuse_attention.fuse_c8(ref_c8, p_nhwc, head=(hd.wf, hd.bf), log_softmax=False)
         return out, p_c8
 
+    def phase2_warp(self, p_nhwc, refs_nhwc, mv_q):
+        """Phase 2 with the MV warp in front (fast path): -> (logits NCHW at feature resolution, p C8)."""
+        hd = self.packed()["head"]
+        p_c8, out = self.fuse_attention.fuse_warp(refs_nhwc, mv_q, p_nhwc, head=(hd.wf, hd.bf), log_softmax=False)
+        return out, p_c8
+
     def forward_phase2(self, p, ref_p):
         self._check_inference()
         out, p_c8 = self.phase2_c8(ops.to_nhwc(p), self._ref_c8(ref_p))

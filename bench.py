@@ -239,16 +239,19 @@ def main():
                     "folded pyramid execute fewer than the reference's direct convs); reference_direct_conv_tflops = the "
                     "reference's direct-convolution FLOP count (SURVEY 8d) / (conv kernel + Winograd transform time)",
         }
-        cre, wrp = nk["creff"], nk["warp_mvq"]
         # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
         C, fd = cfg["C"], cfg["feat_div"]
         Hp, Wp = H // fd, W // fd
         logit_px = Hp * Wp if cfg["kind"] == "semseg" else H * W              # pspnet_semseg phase 2 returns logits at feature resolution
         stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
         nb = 3 * len(runner.plan)                                         # frames covered by the profiled launches
+        zero = {"ms": 0.0, "flops": 0}
+        fused = "creff_warp" in nk                                        # C == 64: one kernel (warp fused into the tile staging)
+        cre, wrp = nk.get("creff_warp", nk.get("creff", zero)), nk.get("warp_mvq", zero)
         stage_ms = (cre["ms"] + wrp["ms"]) / nb
         result["roofline_creff"] = {
-            "kernel": "warp_mvq_nhwc_kernel + " + ("creff_mfma_kernel<NB>" if C >= 128 else "creff_kernel<7,NC,TH>") + " (MV warp + fused CReFF + classifier)",
+            "kernel": ("creff_rr_kernel<NB> (MV warp + CReFF + classifier, one kernel)" if fused else
+                       "warp_mvq_nhwc_kernel + " + ("creff_mfma_kernel<NB>" if C >= 128 else "creff_kernel<7,NC,TH>") + " (MV warp, then fused CReFF + classifier)"),
             "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
             "algorithmic_bytes_per_frame": stage_bytes, "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
