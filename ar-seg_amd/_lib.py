@@ -12,6 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARSEG_HIP_LIB", os.path.join(_HERE, "lib", "libarseg_hip.so"))   # env override: kernel experiments
 
+ABI_VERSION = 2          # ARSEG_ABI_VERSION of include/arseg_hip.h
 ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 NCHW, NHWC, C8 = 0, 1, 2
@@ -42,8 +43,10 @@ PROTOTYPES = {
     "arseg_local_weighting_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_warp_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_mv_resize_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_flow_resize_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_warp_mvq_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_creff_fwd": (c_int, [_P] * 8 + [_P, _P, _P, c_int, _P, c_int] + [c_int] * 8 + [_STREAM]),
+    "arseg_creff_fwd_ex": (c_int, [_P] * 8 + [_P, _P, _P, c_int, _P, c_int] + [c_int] * 10 + [_STREAM]),
     "arseg_creff_warp_fwd": (c_int, [_P, _P, c_int, c_int, _P] + [_P] * 6 + [_P, c_int, _P, _P, c_int, _P, c_int] + [c_int] * 8 + [_STREAM]),
     "arseg_to_c8_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _STREAM]),
     "arseg_from_c8_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
@@ -72,7 +75,7 @@ PROTOTYPES = {
     "arseg_merge_motion_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_nchw_to_nhwc_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_nhwc_to_nchw_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _STREAM]),
-    "arseg_argmax_confusion_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 7 + [_STREAM]),
+    "arseg_argmax_confusion_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_STREAM]),
 }
 
 _lib = None
@@ -94,8 +97,8 @@ def load() -> ctypes.CDLL:
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this binding drifted apart
         fn.restype, fn.argtypes = res, args
-    if lib.arseg_version() != 1:
-        raise ArsegError(f"ABI version mismatch: library reports {lib.arseg_version()}, binding expects 1")
+    if lib.arseg_version() != ABI_VERSION:
+        raise ArsegError(f"ABI version mismatch: library reports {lib.arseg_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

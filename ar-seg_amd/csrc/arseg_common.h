@@ -15,6 +15,19 @@ static inline int arseg_launch_status() {
 static inline hipStream_t arseg_stream(arseg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int arseg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: remember, per device, the largest request that has
+// been granted (a process may drive several GPUs, e.g. under nn.DataParallel).  Grow-only; a race only repeats the same call.
+struct ArsegSmemAttr { size_t granted[32] = {}; };
+static inline int arseg_allow_smem(ArsegSmemAttr &a, const void *kernel, size_t smem) {
+    int dev = -1;
+    const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 32;
+    if (known && smem <= a.granted[dev]) return ARSEG_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    if (known) a.granted[dev] = smem;
+    return ARSEG_OK;
+}
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 

@@ -649,13 +649,8 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
 template <int BM, int BN, int BK, int NBUF, int MATH, int NWM = 2, int NWN = 2>
 int launch(const ConvParams &p, const Plan &pl, hipStream_t st) {
     const size_t smem = (size_t)NBUF * (BM + BN) * (BK + 4) * sizeof(float);
-    static bool attr_set = false;     // idempotent; a race only repeats the same call
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, BK, NBUF, MATH, NWM, NWN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv_igemm_kernel<BM, BN, BK, NBUF, MATH, NWM, NWN>), smem)) return e;
     dim3 grid(pl.tiles_m * pl.tiles_n, p.in_bs || p.w_bs || p.out_bs ? p.N_batch : 1, pl.nsplit);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, NBUF, MATH, NWM, NWN>), grid, dim3(64 * NWM * NWN), smem, st, p);
     return arseg_launch_status();
@@ -673,12 +668,8 @@ template <int BN, int WM>
 int launch_patch(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
     const int tw = pl.patch_tw, th = 64 * WM / tw, npx = (th + 2 * dil) * (tw + 2 * dil);
     const size_t smem = (size_t)((npx * 144 + 255) & ~255) + (size_t)2 * BN * 144;
-    static size_t attr_smem = 0;     // grow-only; a race only repeats the same call
-    if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_patch_kernel<BN, WM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_smem = smem;
-    }
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv3x3_patch_kernel<BN, WM>), smem)) return e;
     int l2 = 0;
     while ((1 << l2) < tw) ++l2;
     hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM>), dim3(pl.tiles_m * pl.tiles_n), dim3(128 * WM), smem, st, p, tw, l2);

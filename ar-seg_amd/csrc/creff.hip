@@ -31,8 +31,6 @@
 // fp32 throughout (VALU); the banded QK^T wastes >75% of an fp32 MFMA tile, which runs at the VALU
 // rate anyway (MI355X_MICROARCH: v_mfma_f32_* = 64 FLOP/clk/SIMD), so MFMA would be slower here.
 #include "creff_params.h"
-#include <cstdlib>
-#include <cstring>
 
 namespace {
 
@@ -443,13 +441,8 @@ int launch_creff(const CreffParams &p, hipStream_t st) {
                            (size_t)G * ((TH + 2) * (TW + 2) + PAD) + 3 * 10 * G;
     const size_t smem = (fl4 + (NC > 0 ? (size_t)p.n_cls * (p.C >> 2) : 0)) * sizeof(f32x4);
     if (smem > 160 * 1024) return ARSEG_EUNSUPPORTED;
-    static size_t attr_smem = 0;     // grow-only; a race only repeats the same call
-    if (smem > attr_smem) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_kernel<KS, NC, TH>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_smem = smem;
-    }
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(creff_kernel<KS, NC, TH>), smem)) return e;
     dim3 grid(arseg_cdiv(p.Wp, TW), arseg_cdiv(p.Hp, TH), p.N);
     hipLaunchKernelGGL((creff_kernel<KS, NC, TH>), grid, dim3(16 * TH), smem, st, p);
     return arseg_launch_status();
@@ -504,15 +497,16 @@ __global__ __launch_bounds__(256) void nhwc_c8_kernel(const float *__restrict__ 
 
 }  // namespace
 
-extern "C" int arseg_creff_fwd(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
-                               const float *bk, const float *wv, const float *bv, float *p_out, const float *wf,
-                               const float *bf, int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp,
-                               int hp, int wp, int kH, int kW, arseg_stream_t stream) {
+extern "C" int arseg_creff_fwd_ex(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
+                                  const float *bk, const float *wv, const float *bv, float *p_out, const float *wf,
+                                  const float *bf, int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp,
+                                  int hp, int wp, int kH, int kW, int impl, int mfma_tile_rows, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(hr); ARSEG_CHECK_PTR(lr); ARSEG_CHECK_PTR(wq); ARSEG_CHECK_PTR(bq); ARSEG_CHECK_PTR(wk); ARSEG_CHECK_PTR(bk);
     ARSEG_CHECK_PTR(wv); ARSEG_CHECK_PTR(bv); ARSEG_CHECK_PTR(p_out);
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp); ARSEG_CHECK_POS(hp); ARSEG_CHECK_POS(wp);
     if (C & 7) return ARSEG_EUNSUPPORTED;
     if (kH != kW || (kH != 3 && kH != 5 && kH != 7)) return ARSEG_EUNSUPPORTED;
+    if (impl < ARSEG_CREFF_AUTO || impl > ARSEG_CREFF_VALU || (mfma_tile_rows != 0 && mfma_tile_rows != 8 && mfma_tile_rows != 16)) return ARSEG_EINVAL;
     if (N > 65535) return ARSEG_EUNSUPPORTED;
     if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31)) return ARSEG_EUNSUPPORTED;   // 32-bit buffer offsets
     if (!ARSEG_ALIGNED16(hr) || !ARSEG_ALIGNED16(lr) || !ARSEG_ALIGNED16(p_out) || !ARSEG_ALIGNED16(wq) || !ARSEG_ALIGNED16(wk) ||
@@ -530,15 +524,14 @@ extern "C" int arseg_creff_fwd(const float *hr, const float *lr, const float *wq
     p.N = N; p.C = C; p.Hp = Hp; p.Wp = Wp; p.hp = hp; p.wp = wp; p.n_cls = head ? n_cls : 0; p.log_softmax = log_softmax;
     p.p_bytes = (unsigned)((size_t)N * C * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)N * n_cls * Hp * Wp * sizeof(float)) : 0u;
     p.sy = arseg_resize_scale(hp, Hp, true); p.sx = arseg_resize_scale(wp, Wp, true);
+    p.mfma_tile_rows = mfma_tile_rows;
     hipStream_t st = arseg_stream(stream);
     if (kH == 7) {
         // Two implementations.  The matrix-core kernel (creff_mfma.hip: 16-wave workgroups, 16x16 tiles) wins on wide features
         // and small maps (BiSeNet, C=256 at 1/8 resolution: 151 us vs 652 us per frame on MI355X); on the 64-channel
-        // full-resolution PSPNet feature the fp32 VALU kernel below is still ahead (363 us vs 388 us).  ARSEG_CREFF_IMPL=mfma|valu
-        // pins one of them (A/B measurements, tests).
-        const char *e = getenv("ARSEG_CREFF_IMPL");      // read per call: tests switch it
-        const int impl = !e ? 0 : (strcmp(e, "mfma") == 0 ? 1 : (strcmp(e, "valu") == 0 ? 2 : 0));
-        if (impl == 1 || (impl == 0 && C >= 128)) {
+        // full-resolution PSPNet feature the fp32 VALU kernel below is still ahead (363 us vs 388 us). 
+        // `impl` pins one of them (A/B measurements, tests).
+        if (impl == ARSEG_CREFF_MFMA || (impl == ARSEG_CREFF_AUTO && C >= 128)) {
             const int st_m = arseg_creff_mfma_launch(p, st);
             if (st_m != ARSEG_EUNSUPPORTED) return st_m;
         }
@@ -549,6 +542,14 @@ extern "C" int arseg_creff_fwd(const float *hr, const float *lr, const float *wq
     }
     if (kH == 5) return head ? dispatch_th<5, 32>(p, st) : dispatch_th<5, 0>(p, st);
     return head ? dispatch_th<3, 32>(p, st) : dispatch_th<3, 0>(p, st);
+}
+
+extern "C" int arseg_creff_fwd(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
+                               const float *bk, const float *wv, const float *bv, float *p_out, const float *wf,
+                               const float *bf, int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp,
+                               int hp, int wp, int kH, int kW, arseg_stream_t stream) {
+    return arseg_creff_fwd_ex(hr, lr, wq, bq, wk, bk, wv, bv, p_out, wf, bf, n_cls, logits, log_softmax, N, C, Hp, Wp, hp, wp, kH, kW,
+                              ARSEG_CREFF_AUTO, 0, stream);
 }
 
 extern "C" int arseg_to_c8_fwd(const float *in, int layout, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream) {

@@ -20,7 +20,6 @@
 // image = the unfold's padding, model/attention.py:56-58), the query convolution is lane-local (each lane convolves the
 // 4 channels of its own query that its B operand needs).
 #include "creff_params.h"
-#include <cstdlib>
 
 namespace {
 
@@ -435,12 +434,8 @@ int launch(const CreffParams &p, hipStream_t st) {
     typedef Geo<TY> GE;
     const size_t smem = ((size_t)GE::HBUF * G * GE::HPL + (size_t)G * GE::LPL + 2 * LWCAP + 2 * 3 * 10 * G + 2 * G * NBA * 16) * sizeof(f32x4) +
                         (GE::LH + LWD) * sizeof(f32x4) + (size_t)G * GE::KPLV * sizeof(u32x4);
-    static bool attr_set = false;     // idempotent; a race only repeats the same call
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_mfma_kernel<NB, TY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(creff_mfma_kernel<NB, TY>), smem)) return e;
     dim3 grid(arseg_cdiv(p.Wp, TX), arseg_cdiv(p.Hp, TY), p.N);
     hipLaunchKernelGGL((creff_mfma_kernel<NB, TY>), grid, dim3(GE::NT), smem, st, p);
     return arseg_launch_status();
@@ -456,9 +451,8 @@ int arseg_creff_mfma_launch(const CreffParams &p, hipStream_t st) {
     if (p.n_cls > 32) return ARSEG_EUNSUPPORTED;
     // 16-row tiles (one 16-wave workgroup per CU) are faster per frame once the launch fills the chip (batched frames:
     // 0.089 vs 0.104 ms per BiSeNet frame); small launches -- a single 128x256 map is 128 such tiles -- do better with
-    // 8-row tiles, twice the workgroups, two per CU (109 vs 151 us).  ARSEG_CREFF_TY=8|16 pins one (tests, measurements).
-    const char *e = getenv("ARSEG_CREFF_TY");
-    const int ty_env = e ? atoi(e) : 0;
+    // 8-row tiles, twice the workgroups, two per CU (109 vs 151 us).  p.mfma_tile_rows = 8 | 16 pins one (tests, measurements).
+    const int ty_env = p.mfma_tile_rows;
     const long long tiles16 = (long long)arseg_cdiv(p.Wp, TX) * arseg_cdiv(p.Hp, 16) * p.N;
     const bool ty8 = ty_env == 8 || (ty_env != 16 && tiles16 < 512);
     if (p.n_cls == 0) return ty8 ? launch<0, 8>(p, st) : launch<0, 16>(p, st);

@@ -8,6 +8,7 @@ struct CreffParams {
     int N, C, Hp, Wp, hp, wp, n_cls, log_softmax;
     unsigned p_bytes, l_bytes;
     float sy, sx;   // align_corners=True source scales (hp-1)/(Hp-1), (wp-1)/(Wp-1)
+    int mfma_tile_rows;   // matrix-core kernel: 0 = choose by launch size, 8 or 16 = pin the tile height
 };
 
 // creff_mfma.hip; returns ARSEG_EUNSUPPORTED for shapes it does not cover (the caller then uses the VALU kernel)

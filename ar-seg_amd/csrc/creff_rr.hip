@@ -536,8 +536,8 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 
 template <int NB>
 int launch(const RRParams &p, hipStream_t st) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(creff_rr_kernel<NB>), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
-    if (e != hipSuccess) return (int)e;
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(creff_rr_kernel<NB>), SMEM_BYTES)) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const long long ntiles = (long long)p.tiles_x * p.tiles_y * p.N;

@@ -390,29 +390,30 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restri
 // ------------------------------------------------------------------ evaluator tail
 __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float *__restrict__ logits, const int64_t *__restrict__ label,
                                                                int32_t *__restrict__ pred, unsigned long long *__restrict__ hist,
-                                                               int N, int n_cls, int h, int w, int H, int W, int ignore_label) {
+                                                               int N, int n_cls, int h, int w, int H, int W, int ignore_label, int align) {
     __shared__ unsigned int lh[1024];
     for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x) lh[i] = 0;
     __syncthreads();
     const long long total = (long long)N * H * W;
-    const float sy = arseg_resize_scale(h, H, true), sx = arseg_resize_scale(w, W, true);
+    const float sy = arseg_resize_scale(h, H, align != 0), sx = arseg_resize_scale(w, W, align != 0);
     const bool same = (h == H && w == W);
     for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
         const int ox = (int)(pix % W), oy = (int)((pix / W) % H), n = (int)(pix / ((long long)W * H));
         int y0 = oy, y1 = oy, x0 = ox, x1 = ox; float ly = 0.f, lx = 0.f;
         if (!same) {
-            arseg_src_index(sy, oy, true, h, y0, y1, ly);
-            arseg_src_index(sx, ox, true, w, x0, x1, lx);
+            arseg_src_index(sy, oy, align != 0, h, y0, y1, ly);
+            arseg_src_index(sx, ox, align != 0, w, x0, x1, lx);
             ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
         }
-        float best = -INFINITY; int bi = 0;
+        // torch.argmax semantics: the first maximum wins, a NaN counts as the maximum (the first NaN wins)
+        float best = -INFINITY; int bi = 0; bool best_nan = false;
         for (int k = 0; k < n_cls; ++k) {
             const float *b = logits + ((size_t)n * n_cls + k) * h * w;
             float v;
             if (same) v = b[(size_t)oy * w + ox];
             else v = (1.f - ly) * ((1.f - lx) * b[(size_t)y0 * w + x0] + lx * b[(size_t)y0 * w + x1]) +
                      ly * ((1.f - lx) * b[(size_t)y1 * w + x0] + lx * b[(size_t)y1 * w + x1]);
-            if (v > best) { best = v; bi = k; }
+            if (!best_nan && (v > best || v != v)) { best = v; bi = k; best_nan = v != v; }
         }
         if (pred) pred[pix] = bi;
         if (hist && label) {
@@ -582,11 +583,11 @@ extern "C" int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, in
 }
 
 extern "C" int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_t *pred, int64_t *hist, int N, int n_cls,
-                                          int h, int w, int H, int W, int ignore_label, arseg_stream_t stream) {
+                                          int h, int w, int H, int W, int ignore_label, int align_corners, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(logits); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(n_cls); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
     if (n_cls > 32) return ARSEG_EUNSUPPORTED;
     if (!pred && !(hist && label)) return ARSEG_EINVAL;
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3(grid_for((long long)N * H * W, 1024)), dim3(256), 0, arseg_stream(stream), logits,
-                       label, pred, reinterpret_cast<unsigned long long *>(hist), N, n_cls, h, w, H, W, ignore_label);
+                       label, pred, reinterpret_cast<unsigned long long *>(hist), N, n_cls, h, w, H, W, ignore_label, align_corners);
     return arseg_launch_status();
 }

@@ -68,6 +68,27 @@ __global__ __launch_bounds__(256) void warp_nchw_kernel(const float *__restrict_
     }
 }
 
+// the same block for a float flow field in pixels (any values, fp32 or fp64 input; the reference's tensor is fp64): both components
+// scaled by Hp/H, bilinear(align_corners=True), arithmetic in fp64
+template <typename FT>
+__global__ __launch_bounds__(256) void flow_resize_kernel(const FT *__restrict__ flow, double *__restrict__ out, int N, int H, int W, int Hp, int Wp) {
+    const long long total = (long long)N * Hp * Wp;
+    const double sy = Hp > 1 ? (double)(H - 1) / (double)(Hp - 1) : 0.0, sx = Wp > 1 ? (double)(W - 1) / (double)(Wp - 1) : 0.0;
+    for (long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x; pix < total; pix += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(pix % Wp), y = (int)((pix / Wp) % Hp), n = (int)(pix / ((long long)Wp * Hp));
+        const FT *f = flow + (size_t)n * H * W * 2;
+        const double ry = sy * y, rx = sx * x;
+        int y0 = min((int)ry, H - 1), x0 = min((int)rx, W - 1);
+        const int y1 = y0 + (y0 < H - 1), x1 = x0 + (x0 < W - 1);
+        const double ly = fmin(fmax(ry - y0, 0.0), 1.0), lx = fmin(fmax(rx - x0, 0.0), 1.0);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            auto val = [&](int yy, int xx) { return (double)f[((size_t)yy * W + xx) * 2 + k] * (double)Hp / (double)H; };   // flow * Hp / H, left to right
+            out[pix * 2 + k] = (1.0 - ly) * ((1.0 - lx) * val(y0, x0) + lx * val(y0, x1)) + ly * ((1.0 - lx) * val(y1, x0) + lx * val(y1, x1));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void mv_resize_kernel(const int16_t *__restrict__ mv, double *__restrict__ out, int N,
                                                         int H, int W, int Hp, int Wp) {
     const long long total = (long long)N * Hp * Wp;
@@ -169,6 +190,19 @@ extern "C" int arseg_mv_resize_fwd(const int16_t *mv_q, double *out, int N, int 
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp);
     hipLaunchKernelGGL(mv_resize_kernel, dim3(grid_for((long long)N * Hp * Wp)), dim3(256), 0, arseg_stream(stream), mv_q,
                        out, N, H, W, Hp, Wp);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_flow_resize_fwd(const void *flow, int flow_dtype, double *out, int N, int H, int W, int Hp, int Wp,
+                                     arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(flow); ARSEG_CHECK_PTR(out);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp);
+    const int g = grid_for((long long)N * Hp * Wp);
+    if (flow_dtype == ARSEG_FLOW_F64)
+        hipLaunchKernelGGL(flow_resize_kernel<double>, dim3(g), dim3(256), 0, arseg_stream(stream), (const double *)flow, out, N, H, W, Hp, Wp);
+    else if (flow_dtype == ARSEG_FLOW_F32)
+        hipLaunchKernelGGL(flow_resize_kernel<float>, dim3(g), dim3(256), 0, arseg_stream(stream), (const float *)flow, out, N, H, W, Hp, Wp);
+    else return ARSEG_EINVAL;
     return arseg_launch_status();
 }
 

@@ -33,13 +33,12 @@ def warpFeature(feature, flow):
 
 
 def resize_flow(flow, Hp, Wp):
-    """evaluation.py:176-180 for a float flow [B,H,W,2] in pixels (any float dtype): both components are scaled by
-    Hp/H, then bilinear(align_corners=True).  The kernel works on the on-disk int16 quarter-pel representation, which
-    is exact for the reference's data (``flow = int16 / 4``, dataset/camvid.py:625)."""
-    q = torch.round(flow * 4)
-    if not torch.equal(q, flow * 4) or q.abs().max() > 32767:
-        raise _lib.ArsegError("resize_flow expects quarter-pel motion vectors (int16/4) as the reference datasets provide")
-    return ops.mv_resize(q.to(torch.int16), Hp, Wp)
+    """evaluation.py:176-180 for a flow [B,H,W,2]: both components are scaled by Hp/H, then bilinear(align_corners=True), in fp64.
+    int16 input = the on-disk quarter-pel representation (``flow = int16 / 4``, dataset/camvid.py:625); float32 / float64 input =
+    pixels, any values (what the reference's DataLoader hands over).  No host synchronisation."""
+    if flow.dtype == torch.int16:
+        return ops.mv_resize(flow, Hp, Wp)
+    return ops.flow_resize(flow, Hp, Wp)
 
 
 def _downscale_hw(H, W, scale):
@@ -54,7 +53,7 @@ class EvalConstRes(object):
         self.scale = scale
 
     def __call__(self, net, dl, n_classes):
-        hist = None
+        hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
         for imgs, label, *_ in dl:
             label = label.cuda()
             imgs = imgs.cuda()
@@ -96,7 +95,7 @@ class EvalAlterRes(object):
         self.hr_forwards = 0
 
     def __call__(self, highres_net, net, dl, n_classes):
-        hist = None
+        hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
         lr_net = _unwrap(net)
         last_ref, last_p = None, None
         for imgs, label, _, ref_imgs, flow in dl:
@@ -151,3 +150,22 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
     h, w = _downscale_hw(H, W, scale)
     feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(imgs, h, w))[-1]     # a3 + phase 1, batched
     return lr_net.phase2_warp(feat, list(ref_ps), mv_qs)               # a2 + a1 (each frame has its own MV map) + CReFF + head
+
+
+def alter_res_batch_pred(lr_net, ref_ps, imgs, mv_qs, scale=0.5, labels=None, hist=None, ignore_label=255):
+    """B non-keyframes through backbone + warp + CReFF + head and the evaluator tail (evaluation.py:201-209) in one go:
+    -> (pred int32 [B,H,W], hist int64 [n_cls,n_cls] | None).  For BiSeNet the head's 1/8-resolution logits go straight into
+    the argmax (x8 upsample fused); the other networks' logits are resized (align_corners=True,
+    the identity for PSPNet) inside the same argmax kernel."""
+    lr_net = _unwrap(lr_net)
+    B, _, H, W = imgs.shape
+    h, w = _downscale_hw(H, W, scale)
+    feat = lr_net.phase1_nhwc4(ops.frame_to_nhwc4(imgs, h, w))[-1]
+    fused_up = hasattr(lr_net, "out_upsample")                       # BiSeNetOutput: head -> nn.Upsample(x8, align_corners=False)
+    if fused_up:
+        lo, _ = lr_net.phase2_warp(feat, list(ref_ps), mv_qs, upsample=False)
+        if (8 * lo.shape[-2], 8 * lo.shape[-1]) != (H, W):               # label size differs from 8x the head: two resizes, not fusable
+            lo, fused_up = ops.resize_nchw(lo, 8 * lo.shape[-2], 8 * lo.shape[-1], _lib.BILINEAR, False), False
+    else:
+        lo, _ = lr_net.phase2_warp(feat, list(ref_ps), mv_qs)
+    return ops.argmax_confusion(lo, labels, H, W, hist, ignore_label, align_corners=not fused_up)

@@ -349,10 +349,14 @@ class BiSeNetV1WithFuse(_BiSeBase):
         N, n_cls, h, w = lo.shape
         return ops.resize_nchw(lo, 8 * h, 8 * w, _lib.BILINEAR, False), p_c8                   # out_upsample
 
-    def phase2_warp(self, mid_nhwc, refs_nhwc, mv_q):
-        """Phase 2 with the MV warp in front (fast path): -> (logits NCHW at full resolution, p C8)."""
+    def phase2_warp(self, mid_nhwc, refs_nhwc, mv_q, upsample=True):
+        """Phase 2 with the MV warp in front (fast path): -> (logits NCHW at full resolution, p C8).  ``upsample=False`` returns the
+        head's logits at 1/8 resolution instead, for a caller that fuses out_upsample (x8 bilinear, align_corners=False,
+        bisenet.py:215-216) into the argmax (ops.argmax_confusion(..., align_corners=False)): 159 MB per frame never written."""
         hd = self.conv_out.packed()
         p_c8, lo = self.fuse_attention.fuse_warp(refs_nhwc, mv_q, mid_nhwc, head=(hd.wf, hd.bf), log_softmax=False)
+        if not upsample:
+            return lo, p_c8
         N, n_cls, h, w = lo.shape
         return ops.resize_nchw(lo, 8 * h, 8 * w, _lib.BILINEAR, False), p_c8                   # out_upsample
 

@@ -213,6 +213,19 @@ def mv_resize(mv_q: torch.Tensor, Hp: int, Wp: int) -> torch.Tensor:
     return out
 
 
+def flow_resize(flow: torch.Tensor, Hp: int, Wp: int) -> torch.Tensor:
+    """float flow [N,H,W,2] in pixels (fp32 / fp64) -> float64 [N,Hp,Wp,2] (evaluation.py:176-180), any values."""
+    _need_gpu(flow, dtype=None)
+    if flow.dtype not in (torch.float32, torch.float64):
+        raise _lib.ArsegError(f"flow must be float32 or float64, got {flow.dtype}")
+    flow = flow.contiguous()
+    N, H, W, _ = flow.shape
+    out = torch.empty((N, Hp, Wp, 2), dtype=torch.float64, device=flow.device)
+    _launch("flow_resize", _lib.load().arseg_flow_resize_fwd, _ptr(flow), _lib.FLOW_F64 if flow.dtype == torch.float64 else _lib.FLOW_F32, _ptr(out),
+            N, H, W, Hp, Wp, _stream())
+    return out
+
+
 def warp_mvq(feature_nhwc: torch.Tensor, mv_q: torch.Tensor, out_layout: int = _lib.C8, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """MV resize + warp fused: NHWC feature [N,Hp,Wp,C], int16 quarter-pel MVs [N,H,W,2] at frame resolution.
     ``out``: optional contiguous destination (e.g. one frame's slot of a batched C8 buffer)."""
@@ -256,9 +269,12 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
         wf, bf = head
         n_cls = wf.shape[0]
         logits = torch.empty((N, n_cls, Hp, Wp), dtype=torch.float32, device=hr_c8.device)
-    _launch("creff", _lib.load().arseg_creff_fwd, _ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
+    # kernel choice: explicit arguments of the ABI; the environment knobs (A/B measurements, tests) are read here, not in the library
+    impl = {"mfma": 1, "valu": 2}.get(os.environ.get("ARSEG_CREFF_IMPL", ""), 0)
+    tile_rows = int(os.environ.get("ARSEG_CREFF_TY", "0") or 0)
+    _launch("creff", _lib.load().arseg_creff_fwd_ex, _ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
                                       _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
-                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, _stream(),
+                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, impl, tile_rows if tile_rows in (8, 16) else 0, _stream(),
             flops=N * Hp * Wp * C * (250 + 2 * n_cls),
             nbytes=4 * N * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp))
     return p_out, logits
@@ -683,8 +699,10 @@ def merge_motion(flows: torch.Tensor, frame_start: int = 0) -> torch.Tensor:
 
 
 def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int, W: int, hist: Optional[torch.Tensor] = None,
-                     ignore_label: int = 255, want_pred: bool = True):
-    """Evaluator tail (evaluation.py:201-209): returns (pred int32 [N,H,W] or None, hist int64 [n_cls,n_cls] or None)."""
+                     ignore_label: int = 255, want_pred: bool = True, align_corners: bool = True):
+    """Evaluator tail (evaluation.py:201-209): returns (pred int32 [N,H,W] or None, hist int64 [n_cls,n_cls] or None).
+    ``align_corners=False``: the resize is BiSeNetOutput's ``nn.Upsample(x8, align_corners=False)`` (model/bisenet.py:215-216) --
+    head logits at 1/8 resolution go straight to the argmax, the full-resolution logits are never written."""
     _need_gpu(logits)
     logits = logits.contiguous()
     N, n_cls, h, w = logits.shape
@@ -695,5 +713,5 @@ def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int
         if hist is None:
             hist = torch.zeros((n_cls, n_cls), dtype=torch.int64, device=logits.device)
     _launch("argmax_confusion", _lib.load().arseg_argmax_confusion_fwd, _ptr(logits), _ptr(label), _ptr(pred), _ptr(hist if label is not None else None), N,
-                                                 n_cls, h, w, H, W, ignore_label, _stream())
+                                                 n_cls, h, w, H, W, ignore_label, 1 if align_corners else 0, _stream())
     return pred, hist

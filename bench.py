@@ -18,10 +18,11 @@ split into hi + lo fp16 (22 significant bits) and three MFMAs per product, fp32 
 measured error vs an fp64 reference 1.5e-6 relative, the fp32 MFMA's is 2.3e-6 -- tests/test_gpu_ops.py); `--conv-math f32`
 runs them on v_mfma_f32_32x32x2_f32 instead.
 
-Extra objects on the JSON line: `roofline` (dominant kernel = the implicit-GEMM conv on the matrix cores), `roofline_creff`
-(warp + CReFF stage against the HBM roofline, algorithmic bytes of SURVEY.md section 8d), `cpu_baseline` (the oracle,
-i.e. a port, timed on the host cores for one non-keyframe of the same clip) and `parity` (max-abs error and argmax
-agreement of that frame against the oracle).
+Extra objects on the JSON line: `roofline` (the dominant kernel of the rocprofv3 kernel stats = the fused MV-warp + CReFF kernel,
+against the HBM roofline with the algorithmic bytes of SURVEY.md section 8d), `roofline_conv` (the conv family against the dense fp16
+MFMA peak, counted in the reference's direct-conv FLOPs), `cpu_baseline` (the oracle, i.e. a port, timed on the host cores for one
+non-keyframe of the same clip: 2 warm-up + 5 timed runs, median), `cpu_baseline_c1` (BASELINE configs[0]: PSPNet-18 HR 720x960 on the
+CPU) and `parity` (max-abs error and argmax agreement of that frame against the oracle).
 """
 import argparse
 import json
@@ -133,7 +134,11 @@ def main():
     frames_b = torch.cat([frames[f] for f in runner.plan])            # this rank's 11 non-keyframes, plan order
     mvs_b = torch.cat([mvs[f] for f in runner.plan])
 
+    fused_tail = cfg["kind"] == "bise"      # BiSeNet: head -> x8 upsample -> argmax fused (the [19,H,W] logits are never written)
+
     def batch_fn(refs, imgs, mvq):
+        if fused_tail:
+            return ev.alter_res_batch_pred(lr, refs, imgs, mvq, SCALE)[0]
         return ev.alter_res_batch_fast(lr, refs, imgs, mvq, SCALE)[0]
 
     def step():
@@ -205,67 +210,102 @@ def main():
         ky = prof_key.summary()
         conv = nk["conv2d"]
         conv_k = ky["conv2d"]
-        tf = lambda r: r["flops"] / (r["ms"] * 1e-3) / 1e12
-        # dominant kernel of the step: conv_igemm_f32 (one batched LR pass of 11 frames + one HR frame).
-        # `achieved` counts the FLOPs the MFMA kernel actually executes (Winograd F(4x4,3x3) and the folded pyramid
-        # execute fewer than the reference's direct convs) over its own time = MFMA utilisation.
+        # ---- conv family (conv_igemm_kernel<...> + conv3x3_patch_kernel<...>): MFMA-bound.  `frac` = the reference's direct-conv FLOP count
+        # (2 x MACs of every conv / linear, hook-counted on the reference: 11 x 116.9 + 468.2 GFLOP per GOP at the headline
+        # config) / the kernels' summed time / the dense fp16 MFMA peak.  `mfma_issue_frac` = what the matrix cores actually execute
+        # (GEMM FLOPs x 3 under f16x3: hi.hi + hi.lo + lo.hi) against the same peak -- issue rate, not work.
         tot_flops = conv["flops"] / 3 + conv_k["flops"]
         tot_ms = conv["ms"] / 3 + conv_k["ms"]
         n_launch = conv["launches"] / 3 + conv_k["launches"]
         wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output")) / 3 + \
             sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
-        ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9          # 2*MACs of every conv/linear of the reference (hook-counted)
-        # f16x3: every GEMM MAC is three fp16 MFMA MACs -> executed matrix-core FLOPs = 3 x the GEMM FLOPs, against the fp16 peak
+        ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9
         mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]
         gemm_tf = tot_flops / (tot_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_conv_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command
+        conv_traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command (profiles/collect.sh)
+        traffic_db = {}
         if os.path.exists(tfile) and args.config == "psp":
             with open(tfile) as f:
-                traffic = json.load(f).get(args.conv_math, {}).get("hbm_bytes_per_launch")
-        result["roofline"] = {
-            "kernel": "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> (implicit GEMM / batched Winograd GEMM; " +
+                traffic_db = json.load(f)
+            conv_traffic = traffic_db.get("conv_all_tiles", {}).get("hbm_bytes_per_launch")
+        ref_tf = ref_flops / (tot_ms * 1e-3) / 1e12 if ref_flops else None
+        result["roofline_conv"] = {
+            "kernel": "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / batched Winograd GEMM; " +
                       {"f16x3": "3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)", "f16": "v_mfma_f32_32x32x16_f16 on fp16-rounded operands)",
                        "f32": "v_mfma_f32_32x32x2_f32)"}[args.conv_math],
-            "bound": "mfma", "achieved": mfma_mult * gemm_tf, "peak": peak, "unit": "TFLOP/s",
-            "frac": mfma_mult * gemm_tf / peak,
-            "traffic": traffic,
-            "fp32_gemm_tflops": gemm_tf, "fp32_gemm_vs_fp32_mfma_peak": gemm_tf / PEAK_FP32_MFMA_TFLOPS,
+            "bound": "mfma", "achieved": ref_tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": ref_tf / peak if ref_tf else None,
+            "frac_incl_winograd_transforms": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12 / peak if ref_flops else None,
+            "mfma_issue_frac": mfma_mult * gemm_tf / peak,
+            "traffic": conv_traffic,
+            "algorithmic_gflop_per_step": ref_flops / 1e9, "conv_ms_per_step": tot_ms, "winograd_transform_ms_per_step": wino_ms,
+            "executed_gemm_tflops": gemm_tf,
             "per_launch": {"avg_gemm_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
-            "lr_batch_gemm_tflops": tf(conv), "hr_frame_gemm_tflops": tf(conv_k),
-            "reference_direct_conv_tflops": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12,
-            "note": "achieved = matrix-core FLOPs executed by the conv kernel (GEMM FLOPs x3 under f16x3) / its time, against the "
-                    "dense MFMA peak of the instruction used; fp32_gemm_tflops = the fp32 GEMM FLOPs it delivers (Winograd and the "
-                    "folded pyramid execute fewer than the reference's direct convs); reference_direct_conv_tflops = the "
-                    "reference's direct-convolution FLOP count (SURVEY 8d) / (conv kernel + Winograd transform time)",
+            "note": "achieved = SURVEY 8d algorithmic FLOPs of one GOP step / summed conv-kernel time of that step (HIP events on the launch stream); "
+                    "executed_gemm_tflops = the fp32 GEMM FLOPs the kernels execute (Winograd and the folded pyramid execute fewer than the "
+                    "reference's direct convs); mfma_issue_frac counts each of those three times (the hi/lo emulation)",
         }
-        # B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe
+        # ---- dominant kernel of the step (rocprofv3 kernel stats, profiles/r02_*_kernel_stats.csv): the warp + CReFF stage, HBM-bound by the
+        # SURVEY 8d accounting.  B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe; one launch = this rank's
+        # batch of non-keyframes.
         C, fd = cfg["C"], cfg["feat_div"]
         Hp, Wp = H // fd, W // fd
         logit_px = Hp * Wp if cfg["kind"] == "semseg" else H * W              # pspnet_semseg phase 2 returns logits at feature resolution
         stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
-        nb = 3 * len(runner.plan)                                         # frames covered by the profiled launches
-        zero = {"ms": 0.0, "flops": 0}
+        nfr = len(runner.plan)
+        nb = 3 * nfr                                                      # frames covered by the profiled launches
+        zero = {"ms": 0.0, "flops": 0, "launches": 1}
         fused = "creff_warp" in nk                                        # C == 64: one kernel (warp fused into the tile staging)
         cre, wrp = nk.get("creff_warp", nk.get("creff", zero)), nk.get("warp_mvq", zero)
         stage_ms = (cre["ms"] + wrp["ms"]) / nb
-        result["roofline_creff"] = {
-            "kernel": ("creff_rr_kernel<NB> (MV warp + CReFF + classifier, one kernel)" if fused else
-                       "warp_mvq_nhwc_kernel + " + ("creff_mfma_kernel<NB>" if C >= 128 else "creff_kernel<7,NC,TH>") + " (MV warp, then fused CReFF + classifier)"),
+        launch_ms = cre["ms"] / cre["launches"]
+        kname = "creff_rr_kernel<NB>" if fused else ("creff_mfma_kernel<NB,TY>" if C >= 128 else "creff_kernel<7,NC,TH>")
+        kt = next((v for k, v in traffic_db.get("kernels", {}).items() if k.startswith(kname.split("<")[0])), None)
+        result["roofline"] = {
+            "kernel": kname + (" (MV warp + CReFF + classifier + log-softmax in one kernel)" if fused else
+                               " (fused CReFF + classifier) behind warp_mvq_nhwc_kernel (MV warp); achieved counts both"),
             "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-            "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, "traffic": None,
-            "algorithmic_bytes_per_frame": stage_bytes, "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
-            "creff_kernel_gflops": cre["flops"] / (cre["ms"] * 1e-3) / 1e9,
+            "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "traffic": (2 * kt["fetch_kib_avg"] + kt["write_kib_avg"]) * 1024 if kt and "fetch_kib_avg" in kt and "write_kib_avg" in kt else None,
+            "algorithmic_bytes_per_unit": stage_bytes, "units_per_launch": nfr, "avg_launch_ms": launch_ms,
+            "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
+            "kernel_gflops": cre["flops"] / (cre["ms"] * 1e-3) / 1e9,
+            "note": "achieved = SURVEY 8d algorithmic bytes per non-keyframe x frames per launch / the kernel's average launch duration (HIP events "
+                    "on the launch stream); traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the rocprofv3 --pmc passes (profiles/r02_traffic.json)",
         }
         result["per_frame_ms"] = {"lr_frame_by_op": {k: v["ms"] / nb for k, v in sorted(nk.items())},
                                   "hr_keyframe_by_op": {k: v["ms"] for k, v in sorted(ky.items())}}
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle (a port) on one non-keyframe of the same clip; also the parity check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import statistics
+
         from oracle import cpu_ref
 
-        # many-core hosts: the oracle's small strip-wise ops stop scaling (and collapse) far below 256 threads
-        ncores = min(16, os.cpu_count() or 1)
+        def cpu_model():
+            try:
+                with open("/proc/cpuinfo") as f:
+                    for line in f:
+                        if line.startswith("model name"):
+                            return line.split(":", 1)[1].strip()
+            except OSError:
+                pass
+            return "unknown"
+
+        def timed(fn, warm=2, reps=5):          # 2 warm-up + 5 timed iterations, median
+            for _ in range(warm):
+                fn()
+            ts = []
+            for _ in range(reps):
+                t1 = time.perf_counter()
+                fn()
+                ts.append(time.perf_counter() - t1)
+            return statistics.median(ts), ts
+
+        # many-core hosts: the oracle's strip-wise ops stop scaling (and collapse) far below 256 threads
+        host_cores = os.cpu_count() or 1
+        ncores = min(int(os.environ.get("ARSEG_CPU_THREADS", "16")), host_cores)
         torch.set_num_threads(ncores)
         g0, d0 = runner.plan[0]
         img = torch.from_numpy(clips[g0]["frames"][d0:d0 + 1])
@@ -276,19 +316,41 @@ def main():
             sd_hr, sd_lr = resolve_aliases(sd_hr), resolve_aliases(sd_lr)
             fwd = {"psp": cpu_ref.pspnet_forward, "bise": cpu_ref.bisenet_forward, "semseg": cpu_ref.semseg_forward}[cfg["kind"]]
             ref_cpu = fwd(sd_hr, key)[-1]                                         # outside the timed sample
-            t1 = time.perf_counter()
-            o_out, o_p, _, _ = cpu_ref.alter_res_step(cfg["kind"], sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
-            cpu_s = time.perf_counter() - t1
+            keep = {}
+
+            def one_frame():
+                keep["r"] = cpu_ref.alter_res_step(cfg["kind"], sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
+
+            reps = (1, 3) if cfg["H"] * cfg["W"] > 512 * 1024 else (2, 5)         # the 1024x2048 extras: a shorter sample
+            cpu_s, samples = timed(one_frame, *reps)
+            o_out, o_p, _, _ = keep["r"]
+        if fused_tail:          # the timed step ends in the fused argmax; the logits for the parity figure come from one extra untimed pass
+            with torch.no_grad():
+                pred0 = outs[0:1].cpu().long()
+                outs = ev.alter_res_batch_fast(lr, [key_fn(keyframes[g0])], frames_b[0:1], mvs_b[0:1], SCALE)[0]
         got = outs[0:1].cpu()                                              # plan[0] is the first frame of the batch
         ref_gpu = ops.as_nchw(key_fn(keyframes[g0]).unsqueeze(0)).cpu()
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-                                  "sample": "1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same "
-                                            f"{H}x{W} clip with the PyTorch-CPU oracle; keyframe feature precomputed outside the sample",
-                                  "seconds": cpu_s}
+                                  "host_cores": host_cores, "cpu_model": cpu_model(),
+                                  "sample": f"1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same {H}x{W} clip with "
+                                            f"the PyTorch-CPU oracle, keyframe feature precomputed outside the sample; {reps[0]} warm-up + {reps[1]} "
+                                            "timed runs, median",
+                                  "seconds": cpu_s, "seconds_all": samples}
+        if cfg["kind"] == "psp":
+            # BASELINE configs[0]: PSPNet-18 HR branch on one 720x960 CamVid-sized frame, PyTorch-CPU forward, no CReFF (evaluation.py --mode 1 0 0)
+            frame_c1 = torch.from_numpy(synth.make_clip(0, 720, 960, gop=1, mean=mean, std=std)["frames"][0:1])
+            with torch.no_grad():
+                c1_s, c1_all = timed(lambda: cpu_ref.pspnet_forward(sd_hr, frame_c1), 2, 5)
+            result["cpu_baseline_c1"] = {"value": 1.0 / c1_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+                                         "host_cores": host_cores,
+                                         "sample": "BASELINE configs[0]: PSPNet-18 HR forward of one 720x960 frame with the PyTorch-CPU oracle; "
+                                                   "2 warm-up + 5 timed runs, median", "seconds": c1_s, "seconds_all": c1_all}
         result["parity"] = {"max_abs_err_logprobs": float((got - o_out).abs().max()),
                             "max_abs_err_keyframe_feature": float((ref_gpu - ref_cpu).abs().max()),
                             "argmax_agreement": float((got.argmax(1) == o_out.argmax(1)).float().mean()),
                             "tolerance": 1e-3}
+        if fused_tail:
+            result["parity"]["fused_tail_label_agreement"] = float((pred0 == o_out.argmax(1)).float().mean())
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ARSEG_ABI_VERSION 1
+#define ARSEG_ABI_VERSION 2
 
 enum arseg_status {
     ARSEG_OK = 0,
@@ -39,6 +39,7 @@ enum arseg_layout { ARSEG_NCHW = 0, ARSEG_NHWC = 1, ARSEG_C8 = 2 /* [N][C/8][H][
 enum arseg_flow_dtype { ARSEG_FLOW_F32 = 0, ARSEG_FLOW_F64 = 1 };
 enum arseg_resize_mode { ARSEG_NEAREST = 0, ARSEG_BILINEAR = 1 };
 enum arseg_reduce_op { ARSEG_REDUCE_MEAN = 0, ARSEG_REDUCE_MAX = 1 };
+enum arseg_creff_impl { ARSEG_CREFF_AUTO = 0, ARSEG_CREFF_MFMA = 1 /* split-fp16 matrix-core kernel */, ARSEG_CREFF_VALU = 2 /* fp32 VALU kernel */ };
 
 typedef void *arseg_stream_t; /* hipStream_t */
 
@@ -72,6 +73,10 @@ int arseg_warp_fwd(const float *feature, const void *flow, int flow_dtype, float
  * dataset/cityscapes.py:282-285); out: fp64 [N,Hp,Wp,2] = bilinear(align_corners=True) of
  * (mv_q/4) * Hp/H (both components scaled by Hp/H as the reference does). */
 int arseg_mv_resize_fwd(const int16_t *mv_q, double *out, int N, int H, int W, int Hp, int Wp, arseg_stream_t stream);
+
+/* The same block for a float flow field [N,H,W,2] in pixels (fp32 or fp64; the reference's DataLoader hands over fp64 = int16/4):
+ * out fp64 [N,Hp,Wp,2] = bilinear(align_corners=True) of flow * Hp/H, computed in fp64. */
+int arseg_flow_resize_fwd(const void *flow, int flow_dtype, double *out, int N, int H, int W, int Hp, int Wp, arseg_stream_t stream);
 
 /* The two steps above fused (fast path): warp an NHWC feature straight from the int16 MV map;
  * out_layout = ARSEG_NHWC or ARSEG_C8. */
@@ -118,6 +123,13 @@ int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q,
                          const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
                          float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
                          arseg_stream_t stream);
+
+/* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_impl (AUTO: the matrix-core kernel
+ * for C >= 128, the VALU kernel otherwise); mfma_tile_rows = 0 (by launch size), 8 or 16.  No environment variables are read. */
+int arseg_creff_fwd_ex(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
+                       const float *bk, const float *wv, const float *bv, float *p_out, const float *wf, const float *bf,
+                       int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH,
+                       int kW, int impl, int mfma_tile_rows, arseg_stream_t stream);
 
 /* Layout changes to / from C8 at the API boundary (layout = ARSEG_NCHW or ARSEG_NHWC; ld = NHWC channel stride). */
 int arseg_to_c8_fwd(const float *in, int layout, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);
@@ -252,12 +264,18 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluator tail                                                       evaluation.py:201-213
- * logits NCHW [N,n_cls,h,w] -> (bilinear align_corners=True to HxW) -> argmax -> pred int32 [N,H,W]
+ * logits NCHW [N,n_cls,h,w] -> bilinear resize to HxW -> argmax -> pred int32 [N,H,W]
  * and hist[label*n_cls+pred] += 1 for label != ignore_label (hist: int64 [n_cls*n_cls], accumulated).
- * pred or hist/label may be NULL.  softmax before argmax is monotone and omitted.
+ * pred or hist/label may be NULL.
+ *   align_corners != 0: the evaluator's F.interpolate(logits, label_size, align_corners=True) (evaluation.py:201);
+ *   align_corners == 0: nn.Upsample(scale_factor, bilinear, align_corners=False) = BiSeNetOutput.up (model/bisenet.py:215-216),
+ *                       i.e. head -> x8 upsample -> argmax without materialising the [n_cls,H,W] logits (the evaluator's own resize is
+ *                       then the identity: labels have the frame's size).
+ * argmax follows torch.argmax (first maximum wins; NaN counts as maximum).  The reference applies softmax first (evaluation.py:203):
+ * monotone, so the result is the same except for top-two logits closer than fp32 exp() can separate (< 3e-8 apart, |logit| < 0.25).
  * ------------------------------------------------------------------------------------------- */
 int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_t *pred, int64_t *hist, int N,
-                               int n_cls, int h, int w, int H, int W, int ignore_label, arseg_stream_t stream);
+                               int n_cls, int h, int w, int H, int W, int ignore_label, int align_corners, arseg_stream_t stream);
 
 #ifdef __cplusplus
 }

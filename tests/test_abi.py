@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in arseg_hip.h but not exported"
     assert sorted(_lib.PROTOTYPES) == declared, "ctypes binding and header drifted apart"
-    assert lib.arseg_version() == 1
+    assert lib.arseg_version() == 2
     assert b"ok" in lib.arseg_status_string(0) and b"invalid" in lib.arseg_status_string(-1)
 
 
@@ -187,3 +187,24 @@ def test_synthetic_clip_matches_the_reference_mv_format():
     assert not mv[0].any() and (mv % 4 == 0).all() and np.abs(mv).max() <= 150 * 4      # integer-pel, clamped, keyframe has no motion
     c2 = synth.make_clip(0, 64, 96, gop=4)
     assert np.array_equal(c["frames"], c2["frames"]) and np.array_equal(mv, c2["mv"])     # seeded
+
+
+def test_reference_attention_imports_with_shim():
+    """INTEGRATION.md level 1: with shims/ in front of sys.path the UNMODIFIED reference model/attention.py imports, its
+    ``from localAttention import ...`` resolving to the HIP-backed shim and its own ``model`` package staying the reference's."""
+    import subprocess
+    import sys
+
+    ref = "/root/reference"
+    if not os.path.isdir(os.path.join(ref, "model")):
+        pytest.skip("reference tree not present (GPU box)")
+    code = (
+        "import sys; sys.dont_write_bytecode = True\n"
+        f"sys.path.insert(0, {ref!r}); sys.path.insert(0, {os.path.join(ROOT, 'shims')!r})\n"
+        "import localAttention, model.attention as A\n"
+        f"assert localAttention.__file__.startswith({os.path.join(ROOT, 'shims')!r}), localAttention.__file__\n"
+        f"assert A.__file__.startswith({ref!r}), A.__file__\n"
+        "assert A.similar_forward is localAttention.similar_forward and hasattr(A, 'MyAttention')\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
