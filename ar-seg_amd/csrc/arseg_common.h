@@ -31,6 +31,24 @@ static inline int arseg_allow_smem(ArsegSmemAttr &a, const void *kernel, size_t 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef __HIPCC__
+// fp32 -> two fp16: x = hi + lo with hi = fp16(x) rounded toward zero (11 significant bits) and lo = fp16(x - hi), 22 bits together.
+// lo is formed from the fp16 value actually stored (v_fma_mix_f32 reads the packed half directly), so
+//   * |x| up to 131008 = 2 x 65504 is still represented (hi saturates at 65504, lo takes the rest; full 22 bits below 65504);
+//     beyond that the pair clamps -- the documented range of the split-fp16 back ends (include/arseg_hip.h);
+//   * |x| below the fp16 normal range degrades gracefully: the absolute error is at most 2^-24 (6e-8).
+// 8 VALU instructions per 4 values (2 cvt_pkrtz + 4 fma_mix + 2 cvt_pkrtz); the mask / subtract / convert form took 12.
+__device__ __forceinline__ void arseg_split_f16(const f32x4 v, unsigned &h01, unsigned &h23, unsigned &l01, unsigned &l23) {
+    float l0, l1, l2, l3;
+    asm("v_cvt_pkrtz_f16_f32 %0, %6, %7\n\tv_cvt_pkrtz_f16_f32 %1, %8, %9\n\t"
+        "v_fma_mix_f32 %2, %0, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %3, %0, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mix_f32 %4, %1, -1.0, %8 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %5, %1, -1.0, %9 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l0), "=&v"(l1), "=&v"(l2), "=&v"(l3) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+    l01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+    l23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l2, l3));
+}
+#endif
+
 // Bilinear source coordinate exactly as ATen computes it for fp32 tensors
 // (area_pixel_compute_source_index): align_corners -> scale = (in-1)/(out-1) (0 when out == 1),
 // src = scale*dst; otherwise scale = in/out, src = max(scale*(dst+0.5)-0.5, 0).

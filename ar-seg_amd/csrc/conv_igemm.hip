@@ -69,18 +69,11 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope) {
     }
 }
 
-// fp32 x4 -> (hi, lo) fp16 x4 each; hi by truncation (a mask), so x - hi is exact and both converts are exact / RTZ
+// fp32 x4 -> (hi, lo) fp16 x4 each (arseg_common.h: hi = RTZ fp16 of x, lo = fp16 of x - hi; representable range |x| <= 131008)
 __device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo) {
-    float h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFFE000u);
-        l[j] = v[j] - h[j];
-    }
-    hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
-    hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
-    lo.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[0], l[1]));
-    lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
+    unsigned h01, h23, l01, l23;
+    arseg_split_f16(v, h01, h23, l01, l23);
+    hi = uint2{h01, h23}; lo = uint2{l01, l23};
 }
 
 template <int BM, int BN, int BK, int NBUF, int MATH, int NWM = 2, int NWN = 2>      // NWM x NWN waves, wave tile BM/NWM x BN/NWN

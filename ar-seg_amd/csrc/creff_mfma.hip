@@ -47,16 +47,9 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
 
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
-    float h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFFE000u);   // 11 significant bits: exact in fp16
-        l[j] = v[j] - h[j];
-    }
-    hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
-    hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
-    lo.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[0], l[1]));
-    lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
+    unsigned h01, h23, l01, l23;
+    arseg_split_f16(v, h01, h23, l01, l23);
+    hi = u32x2{h01, h23}; lo = u32x2{l01, l23};
 }
 // {hi, lo, hi}: dwords 0..3 are the operand {hi,lo}, dwords 2..5 the swapped operand {lo,hi} -- no register copies
 __device__ __forceinline__ u32x6 pack6(const u32x2 hi, const u32x2 lo) { return u32x6{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y}; }

@@ -61,16 +61,9 @@ struct RRParams {
 };
 
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
-    float h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        h[j] = __uint_as_float(__float_as_uint(v[j]) & 0xFFFFE000u);   // 11 significant bits: exact in fp16
-        l[j] = v[j] - h[j];
-    }
-    hi.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[0], h[1]));
-    hi.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h[2], h[3]));
-    lo.x = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[0], l[1]));
-    lo.y = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l[2], l[3]));
+    unsigned h01, h23, l01, l23;
+    arseg_split_f16(v, h01, h23, l01, l23);
+    hi = u32x2{h01, h23}; lo = u32x2{l01, l23};
 }
 __device__ __forceinline__ h16x8 pack8(const u32x2 a, const u32x2 b) { return __builtin_bit_cast(h16x8, u32x4{a.x, a.y, b.x, b.y}); }
 __device__ __forceinline__ u32x2 lds_tr16(const unsigned char *p) {

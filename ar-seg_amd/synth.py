@@ -33,7 +33,7 @@ def _rng(seed: int, key: str) -> np.random.Generator:
     return np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(seed), zlib.crc32(key.encode())])))
 
 
-def synth_tensor(seed: int, key: str, shape: Tuple[int, ...], is_bn: bool, attn_gain: float = 0.12) -> np.ndarray:
+def synth_tensor(seed: int, key: str, shape: Tuple[int, ...], is_bn: bool, attn_gain: float = 0.12, res_gain: float = 0.3) -> np.ndarray:
     """One tensor of a synthetic state_dict (float32; int64 zeros for BN counters)."""
     g = _rng(seed, key)
     leaf = key.rsplit(".", 1)[-1]
@@ -59,14 +59,14 @@ def synth_tensor(seed: int, key: str, shape: Tuple[int, ...], is_bn: bool, attn_
             # last conv of a residual block: the synthetic BN statistics do not re-normalise, so an unscaled
             # branch would double the variance at every block (x16 in std through ResNet-18) and drive the CReFF
             # scores into a saturated softmax that amplifies fp32 rounding.  Trained nets have O(1) features.
-            std *= 0.3
+            std *= res_gain
         return (std * g.standard_normal(shape)).astype(np.float32)
     if leaf == "bias":
         return (0.05 * g.standard_normal(shape)).astype(np.float32)
     raise ValueError(f"unrecognised state_dict key {key!r}")
 
 
-def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, attn_gain: float = 0.12) -> "OrderedDict[str, np.ndarray]":
+def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0, attn_gain: float = 0.12, res_gain: float = 0.3) -> "OrderedDict[str, np.ndarray]":
     """``spec`` = ordered (key, shape) pairs, e.g. from ``module.state_dict()``."""
     spec = [(k, tuple(s)) for k, s in spec]
     keys = {k for k, _ in spec}
@@ -74,16 +74,17 @@ def synth_state_dict(spec: Iterable[Tuple[str, Tuple[int, ...]]], seed: int = 0,
     for k, s in spec:
         parent = k.rsplit(".", 1)[0] if "." in k else ""
         is_bn = (parent + ".running_mean" if parent else "running_mean") in keys
-        out[k] = synth_tensor(seed, k, s, is_bn, attn_gain)
+        out[k] = synth_tensor(seed, k, s, is_bn, attn_gain, res_gain)
     return out
 
 
-def load_synth_weights(module, seed: int = 0, attn_gain: float = 0.12):
-    """Fill a torch module (reference or ours) in place with the synthetic state_dict."""
+def load_synth_weights(module, seed: int = 0, attn_gain: float = 0.12, res_gain: float = 0.3):
+    """Fill a torch module (reference or ours) in place with the synthetic state_dict.  ``attn_gain`` scales the CReFF depthwise
+    convs, ``res_gain`` the last conv of every residual block; (1.0, 1.0) = plain He initialisation everywhere ("un-damped")."""
     import torch
 
     sd = module.state_dict()
-    syn = synth_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed, attn_gain)
+    syn = synth_state_dict([(k, tuple(v.shape)) for k, v in sd.items()], seed, attn_gain, res_gain)
     module.load_state_dict(OrderedDict((k, torch.from_numpy(v)) for k, v in syn.items()))
     return module
 

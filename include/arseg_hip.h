@@ -169,7 +169,7 @@ typedef struct arseg_conv_desc {
 /* ARSEG_MATH_F32:   v_mfma_f32_32x32x2_f32 on the fp32 operands; w_packed from arseg_pack_conv_weight_host.
  * ARSEG_MATH_F16X3: fp32 emulated on the fp16 matrix cores: x = hi + lo (two fp16, 22 significant bits),
  *                   a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi with fp32 accumulation (error ~2^-21 relative per product,
- *                   operands must satisfy |x| < 65504).  w_packed from arseg_split_weight_f16x3_host, and `scale` must
+ *                   activations must satisfy |x| <= 131008 = 2 x 65504: the hi/lo pair clamps beyond, full 22-bit precision below 65504; |x| below the fp16 normal range carries an absolute error <= 6e-8).  w_packed from arseg_split_weight_f16x3_host, and `scale` must
  *                   carry that function's per-channel chan_mul_inv factor.
  * ARSEG_MATH_F16:   reduced precision: plain fp16 operands (activations rounded to nearest, the hi halves of the same split
  *                   weights), one fp16 MFMA per product, fp32 accumulation; ~1e-3 relative error per conv.  Not used by default. */

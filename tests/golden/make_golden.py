@@ -167,8 +167,68 @@ def gen_g9(manifest):
          sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(out).tobytes()).digest(), dtype=np.uint8))
 
 
+def gen_g10(manifest):
+    """G10: one EvalAlterRes step (evaluation.py:148-215) per network with UN-DAMPED synthetic weights (attn_gain = res_gain = 1.0:
+    plain He initialisation everywhere, sharp softmax) -- the parity bound must also hold away from the conditioned weights of G4-G8."""
+    pspnet = importlib.import_module("model.pspnet")
+    bisenet = importlib.import_module("model.bisenet")
+    evaluation = importlib.import_module("evaluation")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+
+    class Wrap:
+        def __init__(self, m):
+            self.module = m
+
+        def __call__(self, *a, **k):
+            return self.module(*a, **k)
+
+    with torch.no_grad():
+        print("G10 un-damped EvalAlterRes")
+        for kind, H, W, mean, std in (("psp", 48, 64, synth.CAMVID_MEAN, synth.CAMVID_STD), ("bise", 64, 128, synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)):
+            if kind == "psp":
+                hr_m = pspnet.PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", pretrained=False).eval()
+                lr_m = pspnet.PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18",
+                                             pretrained=False, atten_k=7).eval()
+            else:
+                hr_m = bisenet.BiSeNetV1(n_classes=12, backend="resnet18").eval()
+                lr_m = bisenet.BiSeNetV1WithFuse(n_classes=12, backend="resnet18").eval()
+            synth.load_synth_weights(hr_m, 20, attn_gain=1.0, res_gain=1.0)
+            synth.load_synth_weights(lr_m, 21, attn_gain=1.0, res_gain=1.0)
+            clip = synth.make_clip(11, H, W, gop=4, mean=mean, std=std)
+            img = torch.from_numpy(clip["frames"][2:3])
+            ref = torch.from_numpy(clip["frames"][0:1])
+            mvq = clip["mv"][2:3]
+            flow = torch.from_numpy(mvq.astype(np.float64) / 4)
+            g = np.random.Generator(np.random.PCG64(901))
+            label = torch.from_numpy(g.integers(0, 12, (1, H, W)).astype(np.int64))
+            captured = {}
+            orig_p2 = lr_m.forward_phase2
+
+            def spy(p, ref_p, _o=orig_p2):
+                r = _o(p, ref_p)
+                captured["lr_p"], captured["warped"], captured["out"], captured["p"] = p, ref_p, r[0], r[1]
+                return r
+
+            lr_m.forward_phase2 = spy
+            miou = evaluation.EvalAlterRes(scale=0.5)(Wrap(hr_m), Wrap(lr_m), [(img, label, None, ref, flow)], 12)
+            lr_m.forward_phase2 = orig_p2
+            logits = F.interpolate(captured["out"], size=label.shape[-2:], mode="bilinear", align_corners=True)
+            preds = torch.argmax(torch.softmax(logits, dim=1), dim=1)
+            sub = 2 if kind == "psp" else 1
+            save(f"g10_undamped_{kind}", img=img, ref=ref, mvq=mvq, label=label, out=captured["out"], preds=preds, miou=np.float64(miou),
+                 warped_s=captured["warped"][..., ::sub, ::sub], lr_p_s=captured["lr_p"][..., ::sub, ::sub], p_s=captured["p"][..., ::sub, ::sub],
+                 abs_max=np.array([float(captured["warped"].abs().max()), float(captured["lr_p"].abs().max()), float(captured["p"].abs().max()),
+                                   float(captured["out"].abs().max())]))
+
+
 def main():
     install_shims()
+    if "--only-g10" in sys.argv:
+        with open(os.path.join(HERE, "manifest.json")) as f:
+            manifest = json.load(f)
+        gen_g10(manifest)
+        return
     if "--only-g9" in sys.argv:
         with open(os.path.join(HERE, "manifest.json")) as f:
             manifest = json.load(f)
@@ -325,6 +385,7 @@ def main():
 
     gen_g8(manifest)
     gen_g9(manifest)
+    gen_g10(manifest)
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=0, sort_keys=True)
     print("done")

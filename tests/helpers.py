@@ -5,9 +5,9 @@ import torch
 from arseg_amd import synth
 
 
-def sd_from_manifest(manifest, name, seed, attn_gain=0.12):
+def sd_from_manifest(manifest, name, seed, attn_gain=0.12, res_gain=0.3):
     spec = [(k, tuple(s)) for k, s in manifest[name]["keys"]]
-    sd = synth.resolve_aliases(synth.synth_state_dict(spec, seed, attn_gain))
+    sd = synth.resolve_aliases(synth.synth_state_dict(spec, seed, attn_gain, res_gain))
     return {k: torch.from_numpy(v) for k, v in sd.items()}
 
 

@@ -1,8 +1,11 @@
 """GPU parity tests, model level: the nn.Module mirrors (same interface as the reference's model/*.py) against the
 golden vectors produced by the reference itself and against the oracle.  Tolerance: 1e-3 abs in fp32 (north star)."""
+import os
+
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from helpers import maxdiff, sd_from_manifest, t
 
@@ -19,32 +22,34 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _psp(manifest, dev, fuse):
+def _psp(manifest, dev, fuse, seed=None, gains=(0.12, 0.3)):
     from arseg_amd.model import PSPNet, PSPNetWithFuse
 
     if fuse:
         m = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
-        name, seed = "PSPNetWithFuse", 1
+        name, dseed = "PSPNetWithFuse", 1
     else:
         m = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
-        name, seed = "PSPNet", 0
+        name, dseed = "PSPNet", 0
+    seed = dseed if seed is None else seed
     from arseg_amd import synth
 
     spec = [(k, tuple(s)) for k, s in manifest[name]["keys"]]
-    sd = {"module." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed).items()}   # DataParallel-style keys
+    sd = {"module." + k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed, *gains).items()}   # DataParallel-style keys
     m = torch.nn.DataParallel(m)
     m.load_state_dict(sd)                                                                              # evaluation.py:41-46
     return m.module.to(dev).eval()
 
 
-def _bise(manifest, dev, fuse):
+def _bise(manifest, dev, fuse, seed=None, gains=(0.12, 0.3)):
     from arseg_amd import synth
     from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse
 
     m = BiSeNetV1WithFuse(n_classes=12, backend="resnet18") if fuse else BiSeNetV1(n_classes=12, backend="resnet18")
-    name, seed = ("BiSeNetV1WithFuse", 3) if fuse else ("BiSeNetV1", 2)
+    name, dseed = ("BiSeNetV1WithFuse", 3) if fuse else ("BiSeNetV1", 2)
+    seed = dseed if seed is None else seed
     spec = [(k, tuple(s)) for k, s in manifest[name]["keys"]]
-    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed).items()})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed, *gains).items()})
     return m.to(dev).eval()
 
 
@@ -181,6 +186,58 @@ def test_eval_alter_res_golden(dev, golden, manifest, kind):
     assert abs(miou_c - manifest[f"g7_{kind}_miou_const"]) <= 2e-3
 
 
+@pytest.mark.parametrize("kind", ["psp", "bise"])
+def test_eval_alter_res_undamped_golden(dev, golden, manifest, kind):
+    """Parity away from the conditioned weights: the reference's EvalAlterRes step with plain He initialisation
+    everywhere (G10: attn_gain = res_gain = 1.0).  Activations reach 100-700 and the CReFF scores q.k reach 1e4-1e5, i.e. one fp32
+    ulp of a score is ~5e-3: the softmax amplifies rounding, and ANY fp32 evaluation -- the reference's own included -- is only
+    defined to ~1e-2 absolute here.  What is asserted:
+      * backbone outputs (keyframe feature, LR feature): |err| <= 1e-5 x magnitude  (measured 4e-6);
+      * the CReFF stage on identical inputs, against an fp64 evaluation of the same formula: the HIP kernel is no further from it
+        than 6x the reference-order fp32 CPU evaluation is (measured 3.4x: the hi/lo fp16 split carries 22 of fp32's 24 significand
+        bits, i.e. 4x the operand rounding; the fp32 VALU kernel measures 2x);
+      * end to end: |err| <= 1e-4 x magnitude and >= 99.8 % identical labels.
+    The 1e-3 absolute bound of the north star is met at the O(1-30) activations of G4-G8; it is NOT meaningful at this conditioning
+    (the measured figures are printed with pytest -s and quoted in DESIGN.md)."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import _lib, ops
+    from oracle import cpu_ref
+
+    g = golden(f"g10_undamped_{kind}")
+    hr = (_psp if kind == "psp" else _bise)(manifest, dev, False, seed=20, gains=(1.0, 1.0))
+    lr = (_psp if kind == "psp" else _bise)(manifest, dev, True, seed=21, gains=(1.0, 1.0))
+    img, ref, label, mvq = t(g["img"]), t(g["ref"]), t(g["label"]), t(g["mvq"])
+    sub = 2 if kind == "psp" else 1
+    a_w, a_lr, a_p, a_o = (float(v) for v in g["abs_max"])
+    sd_hr = sd_from_manifest(manifest, "PSPNet" if kind == "psp" else "BiSeNetV1", 20, 1.0, 1.0)
+    sd_lr = sd_from_manifest(manifest, "PSPNetWithFuse" if kind == "psp" else "BiSeNetV1WithFuse", 21, 1.0, 1.0)
+    with torch.no_grad():
+        o_out, o_p, o_warp, o_ref = cpu_ref.alter_res_step(kind, sd_hr, sd_lr, img, ref, cpu_ref.mv_from_int16(mvq), 0.5)
+        ref_p = hr(ref.to(dev))[-1]
+        out_f, p_c8 = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), 0.5)
+        pred, _ = ops.argmax_confusion(out_f, label.to(dev), label.shape[-2], label.shape[-1])
+        # CReFF stage alone, identical (oracle) inputs, against fp64
+        lr_p = t(g["lr_p_s"]) if sub == 1 else None
+        h, w = img.shape[-2] // 2, img.shape[-1] // 2
+        o_lr = (cpu_ref.pspnet_fuse_phase1 if kind == "psp" else cpu_ref.bisenet_fuse_phase1)(
+            sd_lr, F.interpolate(img, (h, w), mode="bilinear", align_corners=True))[-1]
+        pre = "fuse_attention."
+        sd64 = {k: v.double() for k, v in sd_lr.items() if k.startswith(pre)}
+        p64 = cpu_ref.my_attention(sd64, pre, o_warp.double(), o_lr.double(), 7, 7)
+        p32 = cpu_ref.my_attention(sd_lr, pre, o_warp, o_lr, 7, 7)
+        _, pg = lr.phase2_warp(ops.to_nhwc(o_lr.to(dev)).contiguous(), [ops.to_nhwc(o_ref.to(dev))[0].contiguous()], mvq.to(dev))
+    e_ref = maxdiff(ref_p, o_ref)
+    e_stage_gpu, e_stage_cpu32 = maxdiff(ops.from_c8(pg, _lib.NCHW), p64), maxdiff(p32, p64)
+    e_out, e_p = maxdiff(out_f, g["out"]), maxdiff(ops.from_c8(p_c8, _lib.NCHW)[..., ::sub, ::sub], g["p_s"])
+    agree = float((pred.cpu().long().numpy() == g["preds"]).mean())
+    print(f"\n[undamped {kind}] keyframe feature err {e_ref:.2e} (max {a_w:.0f}); CReFF stage vs fp64: HIP {e_stage_gpu:.2e}, fp32 CPU {e_stage_cpu32:.2e} "
+          f"(max {a_p:.0f}); end to end: logits {e_out:.2e} (max {a_o:.0f}), p {e_p:.2e}, labels equal {agree:.5f}")
+    assert e_ref <= 1e-5 * a_w
+    assert e_stage_gpu <= 6 * e_stage_cpu32 + 1e-6 * a_p
+    assert e_p <= 1e-4 * a_p and e_out <= 1e-4 * a_o
+    assert agree >= 0.998
+
+
 def test_modules_fail_loudly_off_gpu(manifest):
     """No CPU fallback: a forward on CPU tensors / CPU parameters raises instead of silently computing elsewhere."""
     from arseg_amd import _lib
@@ -223,6 +280,58 @@ def test_full_size_properties(dev, kind, H, W):
     crop_hr = ops.to_c8(hr[:, r0 - 8:r1 + 8].contiguous(), _lib.NHWC)
     pc, _ = ops.creff(crop_hr, lr_full[:, r0 - 8:r1 + 8].contiguous(), pa, None, False)
     assert maxdiff(ops.from_c8(pf, _lib.NHWC)[:, r0:r1], ops.from_c8(pc, _lib.NHWC)[:, 8:8 + (r1 - r0)]) <= 1e-5
+
+
+def test_full_size_end_to_end_headline(dev):
+    """BASELINE configs[1] at full size inside the suite: PSPNet-18 keyframe HR forward at 512x1024, one non-keyframe through
+    downscale -> LR backbone (256x512) -> MV warp + CReFF + head (fused kernel) against the CPU oracle, 1e-3 abs (north star);
+    the fused kernel also against the two-kernel path.  ~10 s of CPU oracle on the box's host cores."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+    from oracle import cpu_ref
+
+    H, W = 512, 1024
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    sd_hr = synth.resolve_aliases({k: v.clone() for k, v in hr.state_dict().items()})
+    sd_lr = synth.resolve_aliases({k: v.clone() for k, v in lr.state_dict().items()})
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    clip = synth.make_clip(2, H, W, gop=6, mean=synth.CAMVID_MEAN, std=synth.CAMVID_STD)
+    key, img, mvq = (torch.from_numpy(clip[k][i:i + 1]) for k, i in (("frames", 0), ("frames", 5), ("mv", 5)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        o_out, o_p, _, o_ref = cpu_ref.alter_res_step("psp", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), 0.5)
+        ref_p = hr(key.to(dev))[-1]
+        out, p_c8 = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), 0.5)
+        feat = lr.phase1_nhwc4(ops.frame_to_nhwc4(img.to(dev), H // 2, W // 2))[-1]
+        out2, p2 = lr.phase2_c8(feat, ops.warp_mvq(ops.to_nhwc(ref_p).contiguous(), mvq.to(dev), _lib.C8))      # two-kernel path
+    assert maxdiff(ref_p, o_ref) <= 1e-3
+    assert maxdiff(out, o_out) <= 1e-3 and maxdiff(ops.from_c8(p_c8, _lib.NCHW), o_p) <= 1e-3
+    assert float((out.argmax(1).cpu() == o_out.argmax(1)).float().mean()) >= 0.9999
+    assert maxdiff(out, out2) <= 2e-4 and maxdiff(p_c8, p2) <= 2e-4
+
+
+def test_full_size_hr_720x960(dev):
+    """BASELINE configs[0] shape: PSPNet-18 HR branch on one 720x960 (CamVid) frame, HIP against the CPU oracle, 1e-3 abs."""
+    from arseg_amd import synth
+    from arseg_amd.model import PSPNet
+    from oracle import cpu_ref
+
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    synth.load_synth_weights(hr, 0)
+    sd_hr = synth.resolve_aliases({k: v.clone() for k, v in hr.state_dict().items()})
+    hr = hr.to(dev).eval()
+    x = torch.from_numpy(synth.make_clip(4, 720, 960, gop=1, mean=synth.CAMVID_MEAN, std=synth.CAMVID_STD)["frames"][0:1])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        want = cpu_ref.pspnet_forward(sd_hr, x)
+        got = hr(x.to(dev))
+    assert len(got) == 3 and got[0].shape == (1, 12, 720, 960) and got[2].shape == (1, 64, 720, 960)
+    for a, b in zip(got, want):
+        assert maxdiff(a, b) <= 1e-3
 
 
 @pytest.mark.parametrize("kind", ["psp", "bise"])

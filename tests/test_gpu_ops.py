@@ -532,6 +532,45 @@ def test_conv2d_f16x3_accuracy(dev):
     assert err["f16x3"] < 5e-6 and err["f16x3"] < 2 * err["f32"], err      # measured 1.5e-6 vs 2.3e-6; plain fp16 would be ~1e-3
 
 
+def test_conv2d_f16x3_range_boundaries(dev):
+    """The documented operating range of the split-fp16 back end (include/arseg_hip.h, ARSEG_MATH_F16X3), at its boundaries, against
+    an fp64 reference: (a) activations that are ALL tiny (1e-7 .. 1e-3, fp16-subnormal hi / lo halves): absolute error per product
+    <= 6e-8 |w|; (b) activations up to 1.3e5 (hi saturates at 65504, lo carries the rest): still exact to 22 / 11 bits; (c) beyond
+    131008 the pair clamps: the result is the convolution of the clamped input, not garbage."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(93))
+    w = rnd(94, 64, 64, 3, 3, scale=0.05)
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+
+    def run(x):
+        prev = ops.set_conv_math("f16x3")
+        try:
+            return ops.conv2d(x.permute(0, 2, 3, 1).contiguous().to(dev), pc).permute(0, 3, 1, 2).cpu().double()
+        finally:
+            ops.set_conv_math(prev)
+
+    sign = t(np.where(g.uniform(size=(1, 64, 10, 12)) < 0.5, -1.0, 1.0).astype(np.float32))
+    # (a) all tiny
+    xa = sign * t(np.exp(g.uniform(np.log(1e-7), np.log(1e-3), (1, 64, 10, 12))).astype(np.float32))
+    ea = (run(xa) - F.conv2d(xa.double(), w.double(), padding=1)).abs().max()
+    bound_a = 6e-8 * float(w.abs().sum(dim=(1, 2, 3)).max())                       # sum_k |w_k| * 2^-24 per output
+    assert float(ea) <= bound_a, (float(ea), bound_a)
+    # (b) large: 1e3 .. 1.3e5 (a quarter of the values above 65504)
+    xb = sign * t(np.exp(g.uniform(np.log(1e3), np.log(1.3e5), (1, 64, 10, 12))).astype(np.float32))
+    wb = F.conv2d(xb.double(), w.double(), padding=1)
+    eb = float((run(xb) - wb).abs().max() / wb.abs().max())
+    assert eb <= 5e-4, eb                                                           # 11-bit lo above 65504 (2^-12 relative); ~1e-6 below
+    xb2 = xb.clamp(-6.5e4, 6.5e4)
+    wb2 = F.conv2d(xb2.double(), w.double(), padding=1)
+    assert float((run(xb2) - wb2).abs().max() / wb2.abs().max()) <= 5e-6           # full precision up to 65504
+    # (c) beyond the range: a documented clamp at +-131008
+    xc = xb * 4.0
+    wc = F.conv2d(xc.clamp(-131008.0, 131008.0).double(), w.double(), padding=1)
+    assert float((run(xc) - wc).abs().max() / wc.abs().max()) <= 5e-4
+
+
 @pytest.mark.parametrize("H,W,h,w", [(36, 48, 18, 24), (35, 47, 17, 23), (20, 30, 20, 30)])
 def test_frame_u8_ingest(dev, H, W, h, w):
     """uint8 HWC -> normalised NHWC4 in one kernel == ToTensor + Normalize + F.interpolate(align_corners=True) of the oracle,

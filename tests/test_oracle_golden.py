@@ -150,6 +150,24 @@ def test_g7_alter_res_step(golden, manifest, kind, hr_name, hr_seed, lr_name, lr
     assert float((hist - t(g["hist"])).abs().sum()) <= 4
 
 
+@pytest.mark.parametrize("kind,hr_name,lr_name", [("psp", "PSPNet", "PSPNetWithFuse"), ("bise", "BiSeNetV1", "BiSeNetV1WithFuse")])
+def test_g10_undamped_alter_res_step(golden, manifest, kind, hr_name, lr_name):
+    """The oracle against the reference on UN-DAMPED weights (plain He initialisation: activations reach 200-700, the CReFF softmax
+    is sharp).  Tolerances are relative to the tensor's own magnitude: two fp32 CPU evaluations of the same network already
+    differ by ~1e-6 of it."""
+    g = golden(f"g10_undamped_{kind}")
+    sd_hr = sd_from_manifest(manifest, hr_name, 20, attn_gain=1.0, res_gain=1.0)
+    sd_lr = sd_from_manifest(manifest, lr_name, 21, attn_gain=1.0, res_gain=1.0)
+    out, p, warped, _ = cpu_ref.alter_res_step(kind, sd_hr, sd_lr, t(g["img"]), t(g["ref"]), cpu_ref.mv_from_int16(t(g["mvq"])), 0.5)
+    sub = 2 if kind == "psp" else 1
+    a_w, a_lr, a_p, a_o = (float(v) for v in g["abs_max"])
+    assert maxdiff(warped[..., ::sub, ::sub], g["warped_s"]) <= 2e-6 * a_w
+    assert maxdiff(p[..., ::sub, ::sub], g["p_s"]) <= 2e-6 * a_p
+    assert maxdiff(out, g["out"]) <= 2e-6 * a_o
+    preds, _ = cpu_ref.eval_tail(out, t(g["label"]), 12)
+    assert (preds.numpy() != g["preds"]).mean() <= 1e-3
+
+
 def test_g9_merge_motion(golden):
     """mergeMotion restatement vs the reference function's own output on the same seeded 720x960 motion fields (G9):
     strided sample, a dense crop of the last frame and the SHA-256 of the full int32 array."""
