@@ -20,6 +20,7 @@ FLOW_F32, FLOW_F64 = 0, 1
 NEAREST, BILINEAR = 0, 1
 REDUCE_MEAN, REDUCE_MAX = 0, 1
 MATH_F32, MATH_F16X3, MATH_F16 = 0, 1, 2
+DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
 class ConvDesc(Structure):
@@ -62,6 +63,17 @@ PROTOTYPES = {
     "arseg_split_weight_f16x3_host": (c_int, [_P, c_int, c_int, _P, _P]),
     "arseg_fold_bn_host": (c_int, [_P, _P, _P, _P, c_float, _P, c_int, _P, _P]),
     "arseg_pack_dw3x3_host": (c_int, [_P, c_int, _P]),
+    "arseg_packed_k16": (c_int, [c_int, c_int, c_int]),
+    "arseg_pack_conv_weight16_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "arseg_conv2d16_fwd": (c_int, [POINTER(ConvDesc), c_int, _P, _P, _P, _P, _P, _P, _STREAM]),
+    "arseg_frame_to_nhwc8_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_maxpool3x3s2_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_global_mean16_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_resize16_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),
+    "arseg_scale_add16_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_head16_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_cast_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, _STREAM]),
+    "arseg_warp_mvq16_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_psp_prior_sum_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),

@@ -32,6 +32,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef __HIPCC__
+// 16-bit storage element <-> fp32 (BF = true: bfloat16, false: IEEE fp16); conversions to 16 bits round to nearest even
+template <bool BF>
+__device__ __forceinline__ float arseg_h2f(uint16_t v) {
+    if constexpr (BF) return __uint_as_float((unsigned)v << 16);
+    else return (float)__builtin_bit_cast(_Float16, v);
+}
+template <bool BF>
+__device__ __forceinline__ uint16_t arseg_f2h(float x) {
+    if constexpr (BF) {
+        const unsigned u = __float_as_uint(x);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);      // NaN stays NaN
+        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    } else {
+        return __builtin_bit_cast(uint16_t, (_Float16)x);
+    }
+}
+
 // fp32 -> two fp16: x = hi + lo with hi = fp16(x) rounded toward zero (11 significant bits) and lo = fp16(x - hi), 22 bits together.
 // lo is formed from the fp16 value actually stored (v_fma_mix_f32 reads the packed half directly), so
 //   * |x| up to 131008 = 2 x 65504 is still represented (hi saturates at 65504, lo takes the rest; full 22 bits below 65504);

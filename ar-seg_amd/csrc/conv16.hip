@@ -1,0 +1,253 @@
+// conv2d (+ folded BatchNorm / bias, + residual, + activation) on 16-bit tensors: the bf16 / fp16 storage configurations of
+// BASELINE.json (configs[2]: BiSeNet-18 bf16, configs[4]: BiSeNet-18 0.3x fp16).  Replaces the nn.Conv2d / BatchNorm2d / ReLU stacks of
+// model/bisenet.py:31-60,162-399 (and every other conv of the path) when the network runs with 16-bit activations and weights.
+//
+// Implicit GEMM, one v_mfma_f32_32x32x16_{f16,bf16} per 16-deep product, fp32 accumulation, fp32 epilogue, one rounding to 16 bits at
+// the store.  The GEMM is computed transposed, D[co][pixel] = sum_k W[co][k] * X[pixel][k] (A = weights, B = activations): both
+// operands are then K-contiguous rows in memory ([Cout][Kpad] weights, NHWC pixels), i.e. exactly the MFMA A / B fragment (a lane's 8
+// consecutive k), read from LDS with one ds_read_b128.
+//   * tile: CO_T (64 | 128) output channels x 128 pixels, 4 waves, K step 32, double-buffered LDS, register-staged prefetch of the next
+//     K step under the MFMAs of the current one, one barrier per K step;
+//   * im2col by address arithmetic through buffer descriptors: a tap outside the image / a row past M / the K padding get an
+//     out-of-range offset and load zeros (no branches); Cin is a multiple of 8 (a 16-byte piece never straddles a filter tap), RGB frames are
+//     ingested as NHWC8;
+//   * epilogue through LDS: the fp32 accumulators are transposed into [pixel][co] rows so that scale / bias / residual / activation
+//     run on 8 consecutive channels and the store is a coalesced 16-byte vector of a full NHWC row.
+#include "arseg_common.h"
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+struct Conv16Params {
+    const uint16_t *in, *w, *res;
+    const float *scale, *bias;
+    uint16_t *out;
+    int N, H, W, Cin, in_ld, Ho, Wo, Cout, out_ld, res_ld;
+    int R, S, stride, pad, dil;
+    int K, Kpad, M, act;
+    float slope;
+    int tiles_co, tiles_px;
+    unsigned in_bytes, w_bytes;
+};
+
+constexpr int PIX_T = 128, BK = 32, LDK = BK + 8;      // LDS row: 32 halves + 8 pad (80 bytes: ds_read_b128 of 32 rows is conflict free)
+constexpr unsigned OOB = 0x80000000u;
+
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma16(const u32x4 a, const u32x4 b, const f32x16 c) {
+    if constexpr (BF) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    switch (act) {
+        case ARSEG_ACT_RELU: return fmaxf(v, 0.0f);
+        case ARSEG_ACT_PRELU: return v >= 0.0f ? v : v * slope;
+        case ARSEG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        default: return v;
+    }
+}
+
+template <bool BF, int CO_T>
+__global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
+    constexpr int WPX = CO_T == 128 ? 64 : 32;          // pixels per wave (CO_T = 128: 2 x 2 waves of 64 x 64; 64: 1 x 4 waves of 64 x 32)
+    constexpr int TPX = WPX / 32;                       // 32-pixel MFMA tiles per wave
+    constexpr int RA = CO_T / 64;                       // weight rows staged per thread (row0, row0 + 64)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t *As = reinterpret_cast<uint16_t *>(smem);                       // [2][CO_T][LDK]
+    uint16_t *Bs = As + 2 * CO_T * LDK;                                      // [2][PIX_T][LDK]
+    float *Ot = reinterpret_cast<float *>(smem);                             // epilogue: [64 or 128 pixels][CO_T + 4] fp32 (aliases the staging)
+    constexpr int OLD = CO_T + 4;
+
+    // XCD-aware (bijective) remap of the linear block id: XCD x gets a contiguous chunk of tiles
+    const int nblk = p.tiles_co * p.tiles_px;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_px = bid / p.tiles_co, tile_co = bid - tile_px * p.tiles_co;      // co fastest: neighbours share the pixel rows
+    const int px0 = tile_px * PIX_T, co0 = tile_co * CO_T;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    const int chunk = tid & 3, row0 = tid >> 2;          // 16-byte piece of the 64-byte K step; rows row0 and row0 + 64
+
+    // the output pixels whose rows this thread stages (constant over the K loop)
+    int iy0[2], ix0[2], rowoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = px0 + row0 + 64 * i;
+        if (m < p.M) {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.stride - p.pad;
+            ix0[i] = ox * p.stride - p.pad;
+            rowoff[i] = ((n * p.H + iy0[i]) * p.W + ix0[i]) * p.in_ld * 2;      // bytes; may be negative
+        } else {
+            iy0[i] = -(1 << 28); ix0[i] = 0; rowoff[i] = 0;                     // every tap fails the bounds test
+        }
+    }
+    unsigned woff[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int co = co0 + row0 + 64 * i;
+        woff[i] = co < p.Cout ? (unsigned)(co * p.Kpad) * 2u + chunk * 16u : OOB;
+    }
+
+    struct Regs { u32x4 a[RA], b[2]; };
+    auto load = [&](int kt, Regs &r) {
+        const int k = kt * BK + chunk * 8;
+        const int tap = k / p.Cin, ci = k - tap * p.Cin;
+        const int fr = tap / p.S, fs = tap - fr * p.S;
+        const int dy = fr * p.dil, dx = fs * p.dil;
+        const int tapoff = ((dy * p.W + dx) * p.in_ld + ci) * 2;
+        const bool kok = k < p.K;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = kok && (unsigned)(iy0[i] + dy) < (unsigned)p.H && (unsigned)(ix0[i] + dx) < (unsigned)p.W;
+            r.b[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(rowoff[i] + tapoff) : OOB, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < RA; ++i) r.a[i] = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff[i] + (unsigned)kt * (BK * 2u), 0, 0);
+    };
+    auto store = [&](int buf, const Regs &r) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4 *>(As + (buf * CO_T + row0 + 64 * i) * LDK + chunk * 8) = r.a[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4 *>(Bs + (buf * PIX_T + row0 + 64 * i) * LDK + chunk * 8) = r.b[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wco0 = CO_T == 128 ? (wave >> 1) * 64 : 0;
+    const int wpx0 = CO_T == 128 ? (wave & 1) * 64 : wave * 32;
+    f32x16 acc[2][TPX];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TPX; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int ktiles = p.Kpad / BK;
+    Regs rg;
+    load(0, rg);
+    store(0, rg);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < ktiles) load(kt + 1, rg);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            u32x4 a[2], b[TPX];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4 *>(As + (buf * CO_T + wco0 + 32 * i + li) * LDK + kk * 16 + lh * 8);
+#pragma unroll
+            for (int j = 0; j < TPX; ++j) b[j] = *reinterpret_cast<const u32x4 *>(Bs + (buf * PIX_T + wpx0 + 32 * j + li) * LDK + kk * 16 + lh * 8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j) acc[i][j] = mfma16<BF>(a[i], b[j], acc[i][j]);
+        }
+        if (kt + 1 < ktiles) store(buf ^ 1, rg);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[co][px] -> LDS [px][co] fp32 (CO_T = 128: one 64-pixel half at a time) -> scale, bias, residual, activation -> 16 bit
+    constexpr int NPASS = CO_T == 128 ? 2 : 1, PPX = PIX_T / NPASS;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+        if (NPASS == 1 || (wave & 1) == ps) {
+            const int pbase = NPASS == 1 ? wpx0 : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < TPX; ++j)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const int co = wco0 + 32 * i + 8 * q4 + 4 * lh, px = pbase + 32 * j + li;
+                        *reinterpret_cast<f32x4 *>(Ot + px * OLD + co) = f32x4{acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+                    }
+        }
+        __syncthreads();
+        constexpr int ITEMS = PPX * (CO_T / 8);          // 8-channel vectors of this pass
+        for (int it = tid; it < ITEMS; it += 256) {
+            const int px = it / (CO_T / 8), c8 = it - px * (CO_T / 8);
+            const int m = px0 + ps * PPX + px, co = co0 + c8 * 8;
+            if (m < p.M && co < p.Cout) {
+                float v[8];
+                const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8), v1 = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
+                const int nco = min(8, p.Cout - co);
+                u32x4 rres = {0, 0, 0, 0};
+                if (p.res && nco == 8) rres = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.res_ld + co);
+                uint16_t o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = min(co + e, p.Cout - 1);
+                    float x = v[e] * (p.scale ? p.scale[c] : 1.0f) + (p.bias ? p.bias[c] : 0.0f);
+                    if (p.res) {
+                        const uint16_t rb = nco == 8 ? (uint16_t)((e & 1) ? rres[e >> 1] >> 16 : rres[e >> 1] & 0xffffu) : p.res[(size_t)m * p.res_ld + c];
+                        x += arseg_h2f<BF>(rb);
+                    }
+                    o[e] = arseg_f2h<BF>(act_apply(x, p.act, p.slope));
+                }
+                uint16_t *dst = p.out + (size_t)m * p.out_ld + co;
+                if (nco == 8) *reinterpret_cast<u32x4 *>(dst) = u32x4{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16), o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16)};
+                else
+                    for (int e = 0; e < nco; ++e) dst[e] = o[e];
+            }
+        }
+        if (ps + 1 < NPASS) __syncthreads();
+    }
+}
+
+template <bool BF, int CO_T>
+int launch(const Conv16Params &p, hipStream_t st) {
+    const size_t stage = (size_t)2 * (CO_T + PIX_T) * LDK * 2, epi = (size_t)(CO_T == 128 ? 64 : 128) * (CO_T + 4) * 4;
+    const size_t smem = stage > epi ? stage : epi;
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_kernel<BF, CO_T>), smem)) return e;
+    hipLaunchKernelGGL((conv16_kernel<BF, CO_T>), dim3(p.tiles_co * p.tiles_px), dim3(256), smem, st, p);
+    return arseg_launch_status();
+}
+
+}  // namespace
+
+extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,
+                                  const float *bias, const void *residual, void *out, arseg_stream_t stream) {
+    if (!d) return ARSEG_EINVAL;
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(w_packed16); ARSEG_CHECK_PTR(out);
+    ARSEG_CHECK_POS(d->N); ARSEG_CHECK_POS(d->H); ARSEG_CHECK_POS(d->W); ARSEG_CHECK_POS(d->Cin); ARSEG_CHECK_POS(d->Cout);
+    ARSEG_CHECK_POS(d->R); ARSEG_CHECK_POS(d->S); ARSEG_CHECK_POS(d->stride); ARSEG_CHECK_POS(d->dil);
+    if (dtype != ARSEG_DT_F16 && dtype != ARSEG_DT_BF16) return ARSEG_EINVAL;
+    if ((d->Cin & 7) || (d->in_ld & 7) || d->in_ld < d->Cin) return ARSEG_EINVAL;
+    if ((d->out_ld & 7) || d->out_ld < d->Cout || (residual && ((d->res_ld & 7) || d->res_ld < d->Cout))) return ARSEG_EINVAL;
+    if (!ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(w_packed16) || !ARSEG_ALIGNED16(out) || (residual && !ARSEG_ALIGNED16(residual))) return ARSEG_EINVAL;
+    if (d->batch > 1) return ARSEG_EUNSUPPORTED;
+    int Ho, Wo;
+    if (int e = arseg_conv_out_hw(d, &Ho, &Wo)) return e;
+    Conv16Params p;
+    p.in = (const uint16_t *)in; p.w = (const uint16_t *)w_packed16; p.res = (const uint16_t *)residual; p.scale = scale; p.bias = bias;
+    p.out = (uint16_t *)out;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout; p.out_ld = d->out_ld;
+    p.res_ld = d->res_ld; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
+    p.K = d->R * d->S * d->Cin; p.Kpad = (p.K + BK - 1) / BK * BK; p.act = d->act; p.slope = d->prelu_slope;
+    const long long M = (long long)d->N * Ho * Wo;
+    const size_t in_bytes = (size_t)d->N * d->H * d->W * d->in_ld * 2, w_bytes = (size_t)d->Cout * p.Kpad * 2;
+    if (M >= (1ll << 31) || in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return ARSEG_EUNSUPPORTED;       // 32-bit buffer offsets
+    p.M = (int)M; p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
+    const bool wide = d->tile_cfg == 2 || (d->tile_cfg == 0 && d->Cout > 64);
+    const int co_t = wide ? 128 : 64;
+    p.tiles_co = arseg_cdiv(d->Cout, co_t); p.tiles_px = arseg_cdiv(M, PIX_T);
+    hipStream_t st = arseg_stream(stream);
+    if (dtype == ARSEG_DT_BF16) return wide ? launch<true, 128>(p, st) : launch<true, 64>(p, st);
+    return wide ? launch<false, 128>(p, st) : launch<false, 64>(p, st);
+}

@@ -16,9 +16,21 @@ class HipModule(nn.Module):
     ``.cuda()`` / ``.to()``).
     """
 
+    storage_dtype = torch.float32      # activation / weight storage of the forward: float32, or float16 / bfloat16 (set_storage)
+
     def __init__(self):
         super().__init__()
         self._hip_packed = None
+
+    def set_storage(self, dtype):
+        """Run this network with ``dtype`` activations and weights: torch.float32 (default; convs on the split-fp16 or fp32 matrix
+        cores), or torch.float16 / torch.bfloat16 = the 16-bit storage path (BASELINE configs[2] / configs[4]: one MFMA per product, fp32
+        accumulation and epilogue).  Parameters stay fp32 ``nn.Parameter``s -- the state_dict is unchanged -- and are rounded once when
+        they are packed."""
+        if dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            raise _lib.ArsegError(f"unsupported storage dtype {dtype}")
+        self.storage_dtype = dtype
+        return self
 
     def _apply(self, fn, *args, **kwargs):
         self._hip_packed = None

@@ -54,14 +54,7 @@ class MyAttention(HipModule):
         self.softmax = nn.Softmax(dim=3)
         self.kW = kW
         self.kH = kH
-        self.init_weight()
-
-    def init_weight(self):
-        for ly in self.children():
-            if isinstance(ly, nn.Conv2d):
-                nn.init.kaiming_normal_(ly.weight, a=1)
-                if ly.bias is not None:
-                    nn.init.constant_(ly.bias, 0)
+        # (no init_weight: inference only, parameters always come from a state_dict)
 
     def _pack(self, device):
         return packing.PackedAttention(self, device)

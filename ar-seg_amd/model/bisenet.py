@@ -21,14 +21,6 @@ def conv3x3(in_planes, out_planes, stride=1):
     return nn.Conv2d(in_planes, out_planes, kernel_size=3, stride=stride, padding=1, bias=False)
 
 
-def _kaiming(module):
-    for ly in module.children():
-        if isinstance(ly, nn.Conv2d):
-            nn.init.kaiming_normal_(ly.weight, a=1)
-            if ly.bias is not None:
-                nn.init.constant_(ly.bias, 0)
-
-
 class BasicBlock(HipModule):
     """bisenet.py:31-60."""
 
@@ -103,7 +95,6 @@ class ConvBNReLU(HipModule):
         self.conv = nn.Conv2d(in_chan, out_chan, kernel_size=ks, stride=stride, padding=padding, bias=False)
         self.bn = BatchNorm2d(out_chan)
         self.relu = nn.ReLU(inplace=True)
-        _kaiming(self)
 
     def _pack(self, device):
         return PackedConv.from_modules(self.conv, self.bn, _lib.ACT_RELU, device=device)
@@ -121,7 +112,6 @@ class BiSeNetOutput(HipModule):
         self.conv = ConvBNReLU(in_chan, mid_chan, ks=3, stride=1, padding=1)
         self.conv_out = nn.Conv2d(mid_chan, n_classes, kernel_size=1, bias=True)
         self.up = nn.Upsample(scale_factor=up_factor, mode='bilinear', align_corners=False)
-        _kaiming(self)
 
     def _pack(self, device):
         return PackedHead(self.conv_out, device)
@@ -145,7 +135,6 @@ class AttentionRefinementModule(HipModule):
         self.conv = ConvBNReLU(in_chan, out_chan, ks=3, stride=1, padding=1)
         self.conv_atten = nn.Conv2d(out_chan, out_chan, kernel_size=1, bias=False)
         self.bn_atten = BatchNorm2d(out_chan)
-        _kaiming(self)
 
     def _pack(self, device):
         return PackedConv.from_modules(self.conv_atten, self.bn_atten, _lib.ACT_SIGMOID, device=device)
@@ -219,7 +208,6 @@ class FeatureFusionModule(HipModule):
         self.convblk = ConvBNReLU(in_chan, out_chan, ks=1, stride=1, padding=0)
         self.conv = nn.Conv2d(out_chan, out_chan, kernel_size=1, stride=1, padding=0, bias=False)
         self.bn = nn.BatchNorm2d(out_chan)
-        _kaiming(self)
 
     def _pack(self, device):
         return PackedConv.from_modules(self.conv, self.bn, _lib.ACT_SIGMOID, device=device)
@@ -250,7 +238,7 @@ class _BiSeBase(HipModule):
     def _trunk_nhwc(self, x):
         """NCHW frame -> (feat_cp8, feat_cp16, middle_feat), all NHWC."""
         N, C, H, W = x.shape
-        return self._trunk_nhwc4(ops.frame_to_nhwc4(x, H, W))
+        return self._trunk_nhwc4(ops.frame_ingest(x, H, W, self.storage_dtype))
 
     def phase1_nhwc4(self, x4):
         """forward_phase1 on an NHWC4 frame: same outputs as the reference (aux heads included in 'train'
@@ -268,7 +256,7 @@ class _BiSeBase(HipModule):
         w8 = _half(_half(_half(W)))
         h16, w16 = _half(h8), _half(w8)
         ch, cw = 2 * h16, 2 * w16                                  # context-path 1/8 size = 2 x feat16 size
-        fcat = torch.empty((N, ch, cw, 256), dtype=torch.float32, device=x4.device)          # cat([fsp, fcp], 1) in place
+        fcat = torch.empty((N, ch, cw, 256), dtype=x4.dtype, device=x4.device)          # cat([fsp, fcp], 1) in place
         feat_cp8, feat_cp16 = self.cp.forward_nhwc(x4, out16=fcat[..., 128:])
         if (h8, w8) == (ch, cw):
             self.sp.forward_nhwc(x4, out=fcat[..., :128])
@@ -362,6 +350,8 @@ class BiSeNetV1WithFuse(_BiSeBase):
 
     def forward_phase2(self, middle_feat, ref_p):
         self._check_inference()
+        if ops.is16(middle_feat) or ops.is16(ref_p):      # 16-bit storage through the NCHW interface: the CReFF stage itself is fp32
+            middle_feat, ref_p = ops.cast(middle_feat, torch.float32), ops.cast(ref_p, torch.float32)
         ref_c8 = ops.to_c8(ops.to_nhwc(ref_p), _lib.NHWC) if ops.is_nhwc_view(ref_p) else ops.to_c8(ref_p, _lib.NCHW)
         out, p_c8 = self.phase2_c8(ops.to_nhwc(middle_feat), ref_c8)
         return out, ops.as_nchw(ops.from_c8(p_c8, _lib.NHWC))

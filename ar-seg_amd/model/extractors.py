@@ -1,7 +1,6 @@
 """Dilated (stride-8) ResNet-18 feature extractor -- mirror of ``model/extractors.py:35-66,108-158,340-358``."""
 from __future__ import annotations
 
-import math
 
 from torch import nn
 
@@ -53,13 +52,7 @@ class ResNet(HipModule):
         self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
         self.layer3 = self._make_layer(block, 256, layers[2], stride=1, dilation=2)
         self.layer4 = self._make_layer(block, 512, layers[3], stride=1, dilation=4)
-        for m in self.modules():
-            if isinstance(m, nn.Conv2d):
-                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
-                m.weight.data.normal_(0, math.sqrt(2. / n))
-            elif isinstance(m, nn.BatchNorm2d):
-                m.weight.data.fill_(1)
-                m.bias.data.zero_()
+        # (no weight initialisation here: inference only, parameters always come from a state_dict)
 
     def _make_layer(self, block, planes, blocks, stride=1, dilation=1):
         downsample = None

@@ -78,6 +78,52 @@ def _need_gpu(*tensors, dtype=torch.float32):
             raise _lib.ArsegError(f"expected {dtype}, got {t.dtype}")
 
 
+_DT16 = {torch.float16: _lib.DT_F16, torch.bfloat16: _lib.DT_BF16}
+
+
+def is16(t: torch.Tensor) -> bool:
+    """True for the 16-bit storage path (BASELINE configs[2] / configs[4]): fp16 or bf16 NHWC tensors."""
+    return t.dtype in _DT16
+
+
+def _need_gpu16(*tensors):
+    dt = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.ArsegError("arseg_amd ops run on the GPU only (got a CPU tensor); there is no CPU fallback")
+        if t.dtype not in _DT16 or (dt is not None and t.dtype != dt):
+            raise _lib.ArsegError(f"16-bit path: expected tensors of one 16-bit dtype, got {t.dtype}")
+        dt = t.dtype
+    return _DT16[dt]
+
+
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """fp32 <-> fp16 / bf16 element conversion on the GPU (round to nearest even), any shape with numel % 8 == 0."""
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    code = lambda d: _lib.DT_F32 if d == torch.float32 else _DT16[d]
+    _launch("cast", _lib.load().arseg_cast_fwd, _ptr(x), code(x.dtype), _ptr(out), code(dtype), x.numel(), _stream())
+    return out
+
+
+def frame_ingest(img: torch.Tensor, h: int, w: int, dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """NCHW RGB frame -> the conv engine's input at (h,w): NHWC4 fp32, or NHWC8 fp16 / bf16 on the 16-bit storage path."""
+    if dtype == torch.float32:
+        return frame_to_nhwc4(img, h, w)
+    _need_gpu(img)
+    img = img.contiguous()
+    N, C, H, W = img.shape
+    if C != 3:
+        raise _lib.ArsegError("frame_ingest expects 3 input channels")
+    out = torch.empty((N, h, w, 8), dtype=dtype, device=img.device)
+    _launch("frame_to_nhwc8", _lib.load().arseg_frame_to_nhwc8_16_fwd, _ptr(img), _ptr(out), _DT16[dtype], N, H, W, h, w, _stream())
+    return out
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return ctypes.c_void_p(0 if t is None else t.data_ptr())
 
@@ -109,6 +155,9 @@ def is_nhwc_view(x: torch.Tensor) -> bool:
 
 def to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """Logical NCHW tensor -> physical NHWC tensor [N,H,W,C] (zero-copy when already channels_last)."""
+    if is16(x):
+        _need_gpu16(x)
+        return x.permute(0, 2, 3, 1) if is_nhwc_view(x) else x.permute(0, 2, 3, 1).contiguous()
     _need_gpu(x)
     N, C, H, W = x.shape
     if is_nhwc_view(x):
@@ -287,6 +336,21 @@ def creff_warp(refs_nhwc, mv_q: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=
     refs_nhwc: sequence of B un-warped keyframe features, NHWC [Hp,Wp,C] each (frames of one GOP share theirs);
     mv_q: int16 [B,H,W,2]; lr_nhwc: [B,hp,wp,C].  Returns (p in ``p_layout``, logits NCHW or None).  Shapes the fused
     kernel does not cover (C != 64, windows other than 7x7) run as arseg_warp_mvq_fwd + arseg_creff_fwd."""
+    if is16(lr_nhwc):
+        # 16-bit storage path: the warp reads the 16-bit keyframe feature directly (fp32 C8 out), the small LR feature is converted,
+        # the CReFF arithmetic itself stays fp32 (split-fp16 matrix cores): p and the logits come back fp32
+        dt = _need_gpu16(lr_nhwc, *refs_nhwc)
+        _need_gpu(mv_q, dtype=torch.int16)
+        mv_q = mv_q.contiguous()
+        B, hp, wp, C = lr_nhwc.shape
+        Hp, Wp, _ = refs_nhwc[0].shape
+        _, H, W, _ = mv_q.shape
+        ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=lr_nhwc.device)
+        for b in range(B):
+            _launch("warp_mvq", _lib.load().arseg_warp_mvq16_fwd, _ptr(refs_nhwc[b].contiguous()), dt, _ptr(mv_q[b:b + 1]), _ptr(ref_c8[b:b + 1]), 1, C, Hp, Wp,
+                    H, W, _stream(), nbytes=2 * C * Hp * Wp + 4 * C * Hp * Wp + 4 * H * W)
+        p_c8, logits = creff(ref_c8, cast(lr_nhwc, torch.float32), attn, head, log_softmax, kH, kW)
+        return (p_c8 if p_layout == _lib.C8 else from_c8(p_c8, _lib.NHWC)), logits
     _need_gpu(lr_nhwc, *refs_nhwc)
     _need_gpu(mv_q, dtype=torch.int16)
     lr_nhwc, mv_q = lr_nhwc.contiguous(), mv_q.contiguous()
@@ -415,6 +479,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use).
     up2: the conv input is the x2 bilinear (align_corners=False) upsample of ``x`` (PSPUpsample, model/pspnet.py:43-46);
     the Winograd plan applies it inside its input transform, the direct plan materialises it first."""
+    if is16(x):
+        return _conv2d16(x, pc, residual, out, up2, tile_cfg)
     _need_gpu(x, residual, out)
     x_low = None
     if up2:
@@ -468,14 +534,29 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
 
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
         key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
+        wino_ok = getattr(pc, "wino_u", None) is not None and _WINOGRAD
         plan = _conv_plans.get(key)
+        if plan == "wino" and not wino_ok:                      # a persisted Winograd plan with ARSEG_CONV_WINOGRAD=0: re-tune
+            plan = None
         if plan is None:
             plan = _tune_conv(launch, pc, N * Ho * Wo)
-            if getattr(pc, "wino_u", None) is not None and _WINOGRAD:
-                t_direct = _time(lambda: launch(*plan, record=False))
-                launch_wino(record=False)                       # tunes the batched GEMM underneath
-                if _time(lambda: launch_wino(record=False)) < t_direct:
-                    plan = "wino"
+            if plan is None:
+                # nothing could be launched.  The one shape-independent cause is the 2 GiB limit of the kernels' 32-bit buffer
+                # offsets on a large batch: split the batch (as creff does) instead of caching a plan that never ran.
+                if N > 1 and x_low is None and max(x.numel(), out.numel()) * 4 >= (1 << 31):
+                    hN = N // 2
+                    conv2d(x[:hN], pc, None if residual is None else residual[:hN], out[:hN])
+                    conv2d(x[hN:], pc, None if residual is None else residual[hN:], out[hN:])
+                    return out
+                launch(0, 0)                                    # raises the library's own error
+            if wino_ok:
+                try:
+                    t_direct = _time(lambda: launch(*plan, record=False))
+                    launch_wino(record=False)                   # tunes the batched GEMM underneath
+                    if _time(lambda: launch_wino(record=False)) < t_direct:
+                        plan = "wino"
+                except _lib.ArsegError:
+                    pass                                        # the Winograd route does not cover this shape: keep the direct plan
             _conv_plans[key] = plan
         if plan == "wino":
             launch_wino()
@@ -483,6 +564,42 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
             launch(*plan)
     else:
         launch(tile_cfg, split_k)
+    return out
+
+
+def _conv2d16(x, pc, residual, out, up2, tile_cfg=0):
+    """conv2d on the 16-bit storage path: one MFMA per product (arseg_conv2d16_fwd), fp32 epilogue (pc.scale / pc.bias)."""
+    dt = _need_gpu16(x, residual, out)
+    if up2:
+        n_, h_, w_, c_ = x.shape
+        x = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False)
+    N, H, W, Cin = x.shape
+    w16, cin_pad = pc.weights16(x.dtype)
+    if Cin != cin_pad:
+        raise _lib.ArsegError(f"conv (16-bit) expects {cin_pad} input channels (padded to 8), got {Cin}")
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, _nhwc_ld(x)
+    d.Cout = pc.cout
+    d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
+    d.act, d.prelu_slope = pc.act, pc.slope
+    d.tile_cfg = tile_cfg
+    d.out_ld, d.res_ld = pc.cout, pc.cout
+    lib = _lib.load()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    check(lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv_out_hw")
+    Ho, Wo = ho.value, wo.value
+    cout_ld = (pc.cout + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((N, Ho, Wo, cout_ld), dtype=x.dtype, device=x.device)[..., :pc.cout]
+    elif tuple(out.shape) != (N, Ho, Wo, pc.cout):
+        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(N, Ho, Wo, pc.cout)}")
+    d.out_ld = _nhwc_ld(out)
+    if residual is not None:
+        if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
+            raise _lib.ArsegError("residual shape mismatch")
+        d.res_ld = _nhwc_ld(residual)
+    _launch("conv2d", lib.arseg_conv2d16_fwd, ctypes.byref(d), dt, _ptr(x), _ptr(w16), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out),
+            _stream(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
     return out
 
 
@@ -563,13 +680,20 @@ def _tune_conv(launch, pc, m):
             continue
         if t < best_t:
             best, best_t = (cfg, sk), t
-    return best
+    return best if best_t < float("inf") else None          # None: no candidate could be launched (nothing to cache)
 
 
 # ----------------------------------------------------------------------------------------------
 # small layers
 # ----------------------------------------------------------------------------------------------
 def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    if is16(x):
+        dt = _need_gpu16(x)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        out = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
+        _launch("maxpool", _lib.load().arseg_maxpool3x3s2_16_fwd, _ptr(x), _ptr(out), dt, N, H, W, C, _stream())
+        return out
     _need_gpu(x)
     x = x.contiguous()
     N, H, W, C = x.shape
@@ -606,6 +730,14 @@ def psp_prior_sum(t: torch.Tensor, sizes, H: int, W: int) -> torch.Tensor:
 
 def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
     """NHWC -> [N,1,1,C] mean or max over (H,W)."""
+    if is16(x):
+        dt = _need_gpu16(x)
+        if op != _lib.REDUCE_MEAN:
+            raise _lib.ArsegError("16-bit path: only the mean reduction is built (BiSeNet ARM / FFM / conv_avg)")
+        N, H, W, C = x.shape
+        out = torch.empty((N, 1, 1, C), dtype=x.dtype, device=x.device)
+        _launch("global_reduce", _lib.load().arseg_global_mean16_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), dt, N, H, W, C, _stream())
+        return out
     _need_gpu(x)
     N, H, W, C = x.shape
     out = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
@@ -614,6 +746,14 @@ def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
 
 
 def resize_nhwc(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners: bool, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if is16(x):
+        dt = _need_gpu16(x, out)
+        N, H, W, C = x.shape
+        if out is None:
+            out = torch.empty((N, Hout, Wout, C), dtype=x.dtype, device=x.device)
+        _launch("resize_nhwc", _lib.load().arseg_resize16_fwd, _ptr(x), _ptr(out), dt, N, C, H, W, Hout, Wout, mode, 1 if align_corners else 0,
+                _nhwc_ld(x), _nhwc_ld(out), _stream())
+        return out
     _need_gpu(x, out)
     N, H, W, C = x.shape
     if out is None:
@@ -636,6 +776,14 @@ def resize_nchw(x: torch.Tensor, Hout: int, Wout: int, mode: int, align_corners:
 def scale_add(x: torch.Tensor, scale: torch.Tensor, add_full: Optional[torch.Tensor] = None, add_vec: Optional[torch.Tensor] = None
               ) -> torch.Tensor:
     """out = x * scale[n,c] (+ add_full[n,h,w,c]) (+ add_vec[n,c]); x NHWC contiguous, scale/add_vec [N,1,1,C]."""
+    if is16(x):
+        dt = _need_gpu16(x, scale, add_full, add_vec)
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        out = torch.empty_like(x)
+        _launch("scale_add", _lib.load().arseg_scale_add16_fwd, _ptr(x), _ptr(scale.contiguous()), _ptr(None if add_full is None else add_full.contiguous()),
+                _ptr(None if add_vec is None else add_vec.contiguous()), _ptr(out), dt, N, H * W, C, _stream())
+        return out
     _need_gpu(x, scale, add_full, add_vec)
     x = x.contiguous()
     N, H, W, C = x.shape
@@ -649,6 +797,15 @@ def scale_add(x: torch.Tensor, scale: torch.Tensor, add_full: Optional[torch.Ten
 
 def head(p_nhwc: torch.Tensor, wf: torch.Tensor, bf: torch.Tensor, log_softmax: bool) -> torch.Tensor:
     """1x1 classifier on an NHWC feature -> NCHW logits (optionally LogSoftmax over classes)."""
+    if is16(p_nhwc):
+        dt = _need_gpu16(p_nhwc)
+        _need_gpu(wf, bf)
+        N, H, W, C = p_nhwc.shape
+        n_cls = wf.shape[0]
+        out = torch.empty((N, n_cls, H, W), dtype=torch.float32, device=p_nhwc.device)
+        _launch("head", _lib.load().arseg_head16_fwd, _ptr(p_nhwc), _nhwc_ld(p_nhwc), dt, _ptr(wf), _ptr(bf), _ptr(out), N, H * W, C, n_cls,
+                1 if log_softmax else 0, _stream())
+        return out
     _need_gpu(p_nhwc, wf, bf)
     N, H, W, C = p_nhwc.shape
     n_cls = wf.shape[0]

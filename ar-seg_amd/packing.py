@@ -37,6 +37,7 @@ class PackedConv:
         if w.ndim == 2:                      # nn.Linear == 1x1 conv on a 1x1 image
             w = w[:, :, None, None]
         cout, cin, R, S = w.shape
+        self._w_oihw = w                     # host copy (fp32 OIHW) for the lazily built 16-bit packing
         self.cout, self.cin, self.R, self.S = cout, cin, R, S
         self.cin_pad = (cin + 3) // 4 * 4
         self.stride, self.pad, self.dil, self.act, self.slope = int(stride), int(pad), int(dil), int(act), float(slope)
@@ -76,6 +77,21 @@ class PackedConv:
             self.bias = None if cb is None else torch.from_numpy(cb).to(device)
         self.scale_h3 = torch.from_numpy(scale * mul_inv).to(device)
         self.wino_scale_h3 = torch.from_numpy(scale * wino_mul_inv).to(device) if self.wino_u is not None else None
+
+    def weights16(self, dtype):
+        """(weights packed for the 16-bit storage path [Cout][Kpad16] in ``dtype``, padded input channel count); built on first use.
+        Rounded once from the fp32 parameters (round to nearest even); BN stays in the fp32 epilogue (self.scale / self.bias)."""
+        cache = self.__dict__.setdefault("_w16", {})
+        if dtype not in cache:
+            lib = _lib.load()
+            cin_pad = (self.cin + 7) // 8 * 8
+            kpad = lib.arseg_packed_k16(cin_pad, self.R, self.S)
+            packed = np.empty((self.cout, kpad), dtype=np.uint16)
+            code = _lib.DT_BF16 if dtype == torch.bfloat16 else _lib.DT_F16
+            check(lib.arseg_pack_conv_weight16_host(_hp(self._w_oihw), self.cout, self.cin, self.R, self.S, cin_pad, code,
+                                                    ctypes.c_void_p(packed.ctypes.data)), "pack_conv_weight16")
+            cache[dtype] = (torch.from_numpy(packed.view(np.int16)).to(self.w.device).view(dtype), cin_pad)
+        return cache[dtype]
 
     @staticmethod
     def from_modules(conv, bn=None, act=_lib.ACT_NONE, slope=0.0, device="cuda"):

@@ -39,6 +39,7 @@ enum arseg_layout { ARSEG_NCHW = 0, ARSEG_NHWC = 1, ARSEG_C8 = 2 /* [N][C/8][H][
 enum arseg_flow_dtype { ARSEG_FLOW_F32 = 0, ARSEG_FLOW_F64 = 1 };
 enum arseg_resize_mode { ARSEG_NEAREST = 0, ARSEG_BILINEAR = 1 };
 enum arseg_reduce_op { ARSEG_REDUCE_MEAN = 0, ARSEG_REDUCE_MAX = 1 };
+enum arseg_dtype { ARSEG_DT_F32 = 0, ARSEG_DT_F16 = 1, ARSEG_DT_BF16 = 2 };   /* storage element type of the 16-bit entry points */
 enum arseg_creff_impl { ARSEG_CREFF_AUTO = 0, ARSEG_CREFF_MFMA = 1 /* split-fp16 matrix-core kernel */, ARSEG_CREFF_VALU = 2 /* fp32 VALU kernel */ };
 
 typedef void *arseg_stream_t; /* hipStream_t */
@@ -261,6 +262,37 @@ int arseg_merge_motion_fwd(const int16_t *flows, int16_t *out, void *workspace, 
 /* layout changes at the API boundary */
 int arseg_nchw_to_nhwc_fwd(const float *in, float *out, int N, int C, int HW, int out_ld, arseg_stream_t stream);
 int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C, int HW, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 16-bit storage path (BASELINE configs[2]: BiSeNet-18 bf16, configs[4]: BiSeNet-18 0.3x fp16; model/bisenet.py:438-461,546-575).
+ * Activations and weights are NHWC fp16 or bf16 (dtype = ARSEG_DT_F16 | ARSEG_DT_BF16), every product is ONE
+ * v_mfma_f32_32x32x16_{f16,bf16}, accumulation and the epilogue (folded BN scale / bias, residual, activation) are fp32, results are
+ * rounded to 16 bits once, at the store.  Cin % 8 == 0 (frames are ingested as NHWC8), in_ld / out_ld / res_ld % 8 == 0.
+ *   arseg_pack_conv_weight16_host: OIHW fp32 -> [Cout][Kpad16] 16-bit with k = (r*S+s)*Cin_pad + ci, Kpad16 = arseg_packed_k16(...)
+ *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto, 1 = 64-channel tile, 2 = 128-channel tile; split_k / batch unused)
+ * ------------------------------------------------------------------------------------------- */
+int arseg_packed_k16(int Cin_pad, int R, int S);
+int arseg_pack_conv_weight16_host(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host);
+int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,
+                       const float *bias, const void *residual, void *out, arseg_stream_t stream);
+/* The small layers on 16-bit NHWC tensors (C, ld % 8 == 0), same arithmetic as their fp32 counterparts above, fp32 inside:
+ *   frame ingest: NCHW fp32 RGB -> NHWC8 (channels 3..7 zero) + bilinear align_corners=True downscale      evaluation.py:186-188
+ *   maxpool 3x3 s2 p1; torch.mean(x,(2,3)) -> [N][C]; resize (nearest | bilinear, align_corners on / off); x*scale[n,c] (+add_full) (+add_vec[n,c])
+ *   head: 1x1 classifier (fp32 weights) on a 16-bit feature -> fp32 NCHW logits (+ LogSoftmax)
+ *   cast: fp32 <-> 16-bit element conversion (count % 8 == 0)
+ *   warp_mvq16: arseg_warp_mvq_fwd on a 16-bit keyframe feature, fp32 C8 out (the CReFF kernels' input layout) */
+int arseg_frame_to_nhwc8_16_fwd(const float *img, void *out, int dtype, int N, int H, int W, int h, int w, arseg_stream_t stream);
+int arseg_maxpool3x3s2_16_fwd(const void *in, void *out, int dtype, int N, int H, int W, int C, arseg_stream_t stream);
+int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int dtype, int N, int H, int W, int C, arseg_stream_t stream);
+int arseg_resize16_fwd(const void *in, void *out, int dtype, int N, int C, int Hin, int Win, int Hout, int Wout, int mode,
+                       int align_corners, int in_ld, int out_ld, arseg_stream_t stream);
+int arseg_scale_add16_fwd(const void *x, const void *scale, const void *add_full, const void *add_vec, void *out, int dtype, int N,
+                          int HW, int C, arseg_stream_t stream);
+int arseg_head16_fwd(const void *p, int p_ld, int dtype, const float *wf, const float *bf, float *logits, int N, int HW, int C,
+                     int n_cls, int log_softmax, arseg_stream_t stream);
+int arseg_cast_fwd(const void *in, int in_dtype, void *out, int out_dtype, long long count, arseg_stream_t stream);
+int arseg_warp_mvq16_fwd(const void *feature, int dtype, const int16_t *mv_q, float *out_c8, int N, int C, int Hp, int Wp, int H,
+                         int W, arseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluator tail                                                       evaluation.py:201-213

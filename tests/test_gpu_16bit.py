@@ -1,0 +1,206 @@
+"""GPU parity tests of the 16-bit storage path (BASELINE configs[2]: BiSeNet-18 bf16, configs[4]: BiSeNet-18 0.3x fp16).
+
+Op level: every 16-bit kernel against fp64 torch arithmetic on the SAME 16-bit-rounded operands -- what remains is fp32
+accumulation order and the single output rounding (half an ulp: at most 2^-8 relative for bf16, 2^-11 for fp16).
+Model level: the reference-generated fixtures G6 / G7 (fp32) with the measured error and the label agreement stated per dtype."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import maxdiff, t
+
+pytestmark = pytest.mark.gpu
+DTYPES = [torch.float16, torch.bfloat16]
+ULP = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}          # spacing relative to the bottom of a binade; one rounding to nearest errs <= ULP / 2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from arseg_amd import _lib
+
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def rnd(seed, *shape, scale=1.0):
+    g = np.random.Generator(np.random.PCG64(seed))
+    return torch.from_numpy((scale * g.standard_normal(shape)).astype(np.float32))
+
+
+def close16(got, want, dtype, extra=0.0):
+    """|got - want| <= ulp/2 * |want| + (fp32 accumulation slack) elementwise."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    tol = ULP[dtype] * 0.51 * want.abs() + extra + 1e-6
+    bad = (got - want).abs() > tol
+    assert not bool(bad.any()), (float((got - want).abs().max()), int(bad.sum()))
+
+
+CASES = [
+    # N, H,  W,  Cin, Cout, k, stride, pad, dil, act,  bn,   bias,  res
+    (1, 33, 47, 3, 64, 7, 2, 3, 1, "relu", True, False, False),      # stem (RGB padded to 8)
+    (2, 20, 24, 64, 64, 3, 1, 1, 1, "relu", True, False, True),      # BasicBlock conv2 + residual
+    (1, 17, 19, 64, 128, 3, 2, 1, 1, "relu", True, False, False),    # stride 2, 128-channel tile
+    (1, 12, 16, 128, 128, 1, 2, 0, 1, "none", True, False, False),   # 1x1 stride-2 downsample
+    (1, 9, 11, 512, 128, 1, 1, 0, 1, "relu", True, False, False),    # conv_avg-like 1x1, deep K
+    (3, 1, 1, 128, 128, 1, 1, 0, 1, "sigmoid", True, False, False),  # attention vector (ARM / FFM)
+    (1, 16, 24, 256, 256, 3, 1, 1, 1, "relu", True, False, False),   # feat_conv_out
+    (1, 30, 40, 64, 72, 3, 1, 2, 2, "prelu", True, True, True),      # dilation, Cout not a multiple of the tile, bias
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c[3]}to{c[4]}k{c[5]}s{c[6]}")
+def test_conv2d16(dev, case, dtype):
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    N, H, W, Cin, Cout, k, stride, pad, dil, act, bn, bias, res = case
+    x = rnd(1, N, Cin, H, W).to(dtype)
+    w = rnd(2, Cout, Cin, k, k, scale=(2.0 / (Cin * k * k)) ** 0.5)
+    b = rnd(3, Cout, scale=0.1) if bias else None
+    bnp = None
+    if bn:
+        g = np.random.Generator(np.random.PCG64(4))
+        bnp = (t(g.uniform(0.75, 1.25, Cout).astype(np.float32)), rnd(5, Cout, scale=0.1), rnd(6, Cout, scale=0.1),
+               t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    code = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "prelu": _lib.ACT_PRELU, "sigmoid": _lib.ACT_SIGMOID}[act]
+    pc = PackedConv(w, b, bnp, stride, pad, dil, code, 0.2, dev)
+    cpad = (Cin + 7) // 8 * 8
+    xn = torch.zeros(N, H, W, cpad, dtype=dtype)
+    xn[..., :Cin] = x.permute(0, 2, 3, 1)
+    y = F.conv2d(x.double(), w.to(dtype).double(), None, stride=stride, padding=pad, dilation=dil)
+    if bn:
+        gam, bet, mu, var = (v.double() for v in bnp)
+        sc = gam / torch.sqrt(var + 1e-5)
+        sh = bet - mu * sc + (b.double() * sc if bias else 0)
+        y = y * sc[None, :, None, None] + sh[None, :, None, None]
+    elif bias:
+        y = y + b.double()[None, :, None, None]
+    r = None
+    if res:
+        r = rnd(7, *y.shape).to(dtype)
+        y = y + r.double()
+    y = {"none": lambda v: v, "relu": torch.relu, "prelu": lambda v: torch.where(v >= 0, v, 0.2 * v), "sigmoid": torch.sigmoid}[act](y)
+    got = ops.conv2d(xn.to(dev), pc, residual=None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev))
+    assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
+    close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_small_layers16(dev, dtype):
+    from arseg_amd import _lib, ops
+
+    x = rnd(10, 2, 19, 26, 64).to(dtype)
+    xd = x.to(dev)
+    xc = x.double().permute(0, 3, 1, 2)
+    # maxpool: exact (a selection)
+    assert torch.equal(ops.maxpool3x3s2(xd).cpu(), F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).to(dtype))
+    # global mean
+    close16(ops.global_reduce(xd, _lib.REDUCE_MEAN)[:, 0, 0], xc.mean(dim=(2, 3)), dtype, extra=1e-6)
+    # resize: nearest x2 exact, bilinear align_corners=True and False
+    assert torch.equal(ops.resize_nhwc(xd, 38, 52, _lib.NEAREST, False).cpu(), F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2.0).permute(0, 2, 3, 1).to(dtype))
+    for (Ho, Wo, al) in ((30, 45, True), (38, 52, False)):
+        want = F.interpolate(xc, (Ho, Wo), mode="bilinear", align_corners=al)
+        close16(ops.resize_nhwc(xd, Ho, Wo, _lib.BILINEAR, al).permute(0, 3, 1, 2), want, dtype, extra=1e-5)
+    # scale_add
+    sc, av, af = rnd(11, 2, 1, 1, 64).to(dtype), rnd(12, 2, 1, 1, 64).to(dtype), rnd(13, 2, 19, 26, 64).to(dtype)
+    want = x.double() * sc.double() + af.double() + av.double()
+    close16(ops.scale_add(xd, sc.to(dev), add_full=af.to(dev), add_vec=av.to(dev)), want, dtype, extra=1e-6)
+    close16(ops.scale_add(xd, sc.to(dev)), x.double() * sc.double(), dtype)
+    # head: fp32 logits
+    wf, bf = rnd(14, 19, 64, scale=0.2), rnd(15, 19, scale=0.1)
+    lg = ops.head(xd, wf.to(dev), bf.to(dev), log_softmax=False)
+    assert lg.dtype == torch.float32 and maxdiff(lg, F.conv2d(xc, wf.double()[:, :, None, None], bf.double())) <= 1e-4
+    # frame ingest (+ downscale) and casts
+    img = rnd(16, 2, 3, 36, 48)
+    want = F.interpolate(img.double(), (18, 24), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
+    got = ops.frame_ingest(img.to(dev), 18, 24, dtype)
+    assert got.shape == (2, 18, 24, 8) and float(got[..., 3:].abs().max()) == 0.0
+    close16(got[..., :3], want, dtype, extra=1e-6)
+    assert torch.equal(ops.cast(ops.cast(xd, torch.float32), dtype), xd) and torch.equal(ops.cast(xd, torch.float32).cpu(), x.float())
+    assert torch.equal(ops.cast(rnd(17, 4, 40).to(dev), dtype).cpu(), rnd(17, 4, 40).to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_warp_mvq16(dev, dtype):
+    """MV resize + warp of a 16-bit keyframe feature (fp32 C8 out) against the oracle's warp of the same rounded feature."""
+    from arseg_amd import _lib, ops
+    from oracle import cpu_ref
+
+    H, W, Hp, Wp, C = 64, 96, 8, 12, 64
+    g = np.random.Generator(np.random.PCG64(9))
+    mvq = torch.from_numpy((g.integers(-12, 13, (1, H, W, 2)) * 4).astype(np.int16))
+    feat = rnd(10, 1, C, Hp, Wp).to(dtype)
+    want = cpu_ref.warp_feature(feat.float(), cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq), Hp, Wp))
+    out = torch.empty((1, C // 8, Hp, Wp, 8), dtype=torch.float32, device=dev)
+    lib = _lib.load()
+    import ctypes
+    feat_d, mvq_d = feat.permute(0, 2, 3, 1).contiguous().to(dev), mvq.to(dev)          # (kept alive across the asynchronous launch)
+    st = lib.arseg_warp_mvq16_fwd(ctypes.c_void_p(feat_d.data_ptr()), ops._DT16[dtype], ctypes.c_void_p(mvq_d.data_ptr()),
+                                  ctypes.c_void_p(out.data_ptr()), 1, C, Hp, Wp, H, W, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    assert maxdiff(ops.from_c8(out, _lib.NCHW), want) <= 1e-5
+
+
+def _bise16(manifest, dev, fuse, dtype):
+    from arseg_amd import synth
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse
+
+    m = BiSeNetV1WithFuse(n_classes=12, backend="resnet18") if fuse else BiSeNetV1(n_classes=12, backend="resnet18")
+    name, seed = ("BiSeNetV1WithFuse", 3) if fuse else ("BiSeNetV1", 2)
+    spec = [(k, tuple(s)) for k, s in manifest[name]["keys"]]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(spec, seed).items()})
+    return m.to(dev).eval().set_storage(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bisenet16_golden(dev, golden, manifest, dtype):
+    """BiSeNetV1 (HR branch) and BiSeNetV1WithFuse phase 1 / phase 2 with 16-bit tensors against the reference's fp32 fixtures
+    (G6): reduced precision by construction -- stated: max-abs error relative to the tensor's magnitude and label agreement."""
+    from arseg_amd import ops
+
+    g = golden("g6_bisenet")
+    hr = _bise16(manifest, dev, False, dtype)
+    with torch.no_grad():
+        out, o16, o32, fuse = hr(t(g["x"]).to(dev))
+    assert out.dtype == torch.float32 and fuse.dtype == dtype and out.shape == g["out"].shape and fuse.shape == g["feat_fuse"].shape
+    rel = {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]            # measured 4e-3 / 3e-2 (x ~4 margin)
+    scale_f, scale_o = float(np.abs(g["feat_fuse"]).max()), float(np.abs(g["out"]).max())
+    e_f, e_o = maxdiff(fuse.float(), g["feat_fuse"]), maxdiff(out, g["out"])
+    agree = float((out.argmax(1).cpu().numpy() == g["out"].argmax(1)).mean())
+    print(f"\\n[{dtype}] BiSeNetV1: feat_fuse err {e_f:.3e} (max {scale_f:.1f}), logits err {e_o:.3e} (max {scale_o:.1f}), labels equal {agree:.4f}")
+    assert e_f <= rel * scale_f and e_o <= rel * scale_o
+    assert agree >= {torch.float16: 0.99, torch.bfloat16: 0.93}[dtype]
+    g2 = golden("g6_bisefuse")
+    lr = _bise16(manifest, dev, True, dtype)
+    with torch.no_grad():
+        a16, a32, mid = lr.forward_phase1(t(g2["x"]).to(dev))
+        ob, pb = lr.forward_phase2(mid, t(g2["ref_p"]).to(dev).to(dtype))
+    e_m, e_ob = maxdiff(mid.float(), g2["mid"]), maxdiff(ob, g2["out"])
+    print(f"[{dtype}] BiSeNetV1WithFuse: mid err {e_m:.3e} (max {float(np.abs(g2['mid']).max()):.1f}), logits err {e_ob:.3e} (max {float(np.abs(g2['out']).max()):.1f})")
+    assert e_m <= rel * float(np.abs(g2["mid"]).max()) and e_ob <= rel * float(np.abs(g2["out"]).max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_alter_res16_golden(dev, golden, manifest, dtype):
+    """One EvalAlterRes step (G7, BiSeNet) on the 16-bit fast path: keyframe HR forward, LR backbone, MV warp of the 16-bit keyframe
+    feature, fp32 CReFF, fused argmax tail; against the reference's fp32 logits / labels."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops
+
+    g = golden("g7_alter_bise")
+    hr, lr = _bise16(manifest, dev, False, dtype), _bise16(manifest, dev, True, dtype)
+    img, ref, label, mvq = t(g["img"]), t(g["ref"]), t(g["label"]), t(g["mvq"])
+    with torch.no_grad():
+        ref_p = hr(ref.to(dev))[-1]
+        assert ref_p.dtype == dtype
+        out, _ = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), 0.5)
+        pred, hist = ev.alter_res_batch_pred(lr, [ops.to_nhwc(ref_p)[0]], img.to(dev), mvq.to(dev), 0.5, labels=label.to(dev))
+    e = maxdiff(out, g["out"])
+    agree = float((pred.cpu().long().numpy() == g["preds"]).mean())
+    print(f"\\n[{dtype}] EvalAlterRes step: logits err {e:.3e} (max {float(np.abs(g['out']).max()):.1f}), labels equal {agree:.4f}")
+    assert e <= {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype] * float(np.abs(g["out"]).max())
+    assert agree >= {torch.float16: 0.99, torch.bfloat16: 0.93}[dtype]
+    assert int(hist.sum()) == int((label != 255).sum())
