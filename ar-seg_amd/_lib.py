@@ -68,7 +68,8 @@ PROTOTYPES = {
     "arseg_conv2d16_fwd": (c_int, [POINTER(ConvDesc), c_int, _P, _P, _P, _P, _P, _P, _STREAM]),
     "arseg_frame_to_nhwc8_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_maxpool3x3s2_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
-    "arseg_global_mean16_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_global_mean16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "arseg_global_mean16_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _STREAM]),
     "arseg_resize16_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),
     "arseg_scale_add16_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_head16_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),

@@ -34,7 +34,7 @@ struct Conv16Params {
     unsigned in_bytes, w_bytes;
 };
 
-constexpr int PIX_T = 128, BK = 32, LDK = BK + 8;      // LDS row: 32 halves + 8 pad (80 bytes: ds_read_b128 of 32 rows is conflict free)
+constexpr int PIX_T = 128, KPAD = 64;                  // Kpad16 is a multiple of 64 (both K steps divide it)
 constexpr unsigned OOB = 0x80000000u;
 
 template <bool BF>
@@ -52,11 +52,13 @@ __device__ __forceinline__ float act_apply(float v, int act, float slope) {
     }
 }
 
-template <bool BF, int CO_T>
+template <bool BF, int CO_T, int BK>      // BK: K step (32 | 64 halves); LDS rows carry 8 halves of padding (ds_read_b128 of 32 rows conflict free)
 __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
+    constexpr int LDK = BK + 8, CPR = BK / 8, RPP = 256 / CPR;      // 16-byte pieces per row, rows staged per pass of the workgroup
+    constexpr int RB = PIX_T / RPP;                                 // pixel rows staged per thread
     constexpr int WPX = CO_T == 128 ? 64 : 32;          // pixels per wave (CO_T = 128: 2 x 2 waves of 64 x 64; 64: 1 x 4 waves of 64 x 32)
     constexpr int TPX = WPX / 32;                       // 32-pixel MFMA tiles per wave
-    constexpr int RA = CO_T / 64;                       // weight rows staged per thread (row0, row0 + 64)
+    constexpr int RA = CO_T / RPP;                      // weight rows staged per thread
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint16_t *As = reinterpret_cast<uint16_t *>(smem);                       // [2][CO_T][LDK]
     uint16_t *Bs = As + 2 * CO_T * LDK;                                      // [2][PIX_T][LDK]
@@ -76,13 +78,13 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
 
     const int tid = threadIdx.x;
-    const int chunk = tid & 3, row0 = tid >> 2;          // 16-byte piece of the 64-byte K step; rows row0 and row0 + 64
+    const int chunk = tid % CPR, row0 = tid / CPR;       // 16-byte piece of the K step; rows row0 + RPP * i
 
     // the output pixels whose rows this thread stages (constant over the K loop)
-    int iy0[2], ix0[2], rowoff[2];
+    int iy0[RB], ix0[RB], rowoff[RB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = px0 + row0 + 64 * i;
+    for (int i = 0; i < RB; ++i) {
+        const int m = px0 + row0 + RPP * i;
         if (m < p.M) {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
@@ -97,11 +99,11 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     unsigned woff[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        const int co = co0 + row0 + 64 * i;
+        const int co = co0 + row0 + RPP * i;
         woff[i] = co < p.Cout ? (unsigned)(co * p.Kpad) * 2u + chunk * 16u : OOB;
     }
 
-    struct Regs { u32x4 a[RA], b[2]; };
+    struct Regs { u32x4 a[RA], b[RB]; };
     auto load = [&](int kt, Regs &r) {
         const int k = kt * BK + chunk * 8;
         const int tap = k / p.Cin, ci = k - tap * p.Cin;
@@ -110,7 +112,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
         const int tapoff = ((dy * p.W + dx) * p.in_ld + ci) * 2;
         const bool kok = k < p.K;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             const bool ok = kok && (unsigned)(iy0[i] + dy) < (unsigned)p.H && (unsigned)(ix0[i] + dx) < (unsigned)p.W;
             r.b[i] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(rowoff[i] + tapoff) : OOB, 0, 0);
         }
@@ -119,9 +121,9 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     };
     auto store = [&](int buf, const Regs &r) {
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4 *>(As + (buf * CO_T + row0 + 64 * i) * LDK + chunk * 8) = r.a[i];
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<u32x4 *>(As + (buf * CO_T + row0 + RPP * i) * LDK + chunk * 8) = r.a[i];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4 *>(Bs + (buf * PIX_T + row0 + 64 * i) * LDK + chunk * 8) = r.b[i];
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<u32x4 *>(Bs + (buf * PIX_T + row0 + RPP * i) * LDK + chunk * 8) = r.b[i];
     };
 
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
         const int buf = kt & 1;
         if (kt + 1 < ktiles) load(kt + 1, rg);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 16; ++kk) {
             u32x4 a[2], b[TPX];
 #pragma unroll
             for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4 *>(As + (buf * CO_T + wco0 + 32 * i + li) * LDK + kk * 16 + lh * 8);
@@ -187,14 +189,28 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
                 for (int e = 0; e < 4; ++e) { v[e] = v0[e]; v[4 + e] = v1[e]; }
                 const int nco = min(8, p.Cout - co);
                 u32x4 rres = {0, 0, 0, 0};
-                if (p.res && nco == 8) rres = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.res_ld + co);
+                float sc[8], bi[8];
+                if (nco == 8) {          // the common case: whole 8-channel vectors of scale / bias / residual
+                    const f32x4 s0 = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 s1 = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + co + 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + co + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { sc[e] = s0[e]; sc[4 + e] = s1[e]; bi[e] = b0[e]; bi[4 + e] = b1[e]; }
+                    if (p.res) rres = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.res_ld + co);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = min(co + e, p.Cout - 1);
+                        sc[e] = p.scale ? p.scale[c] : 1.0f; bi[e] = p.bias ? p.bias[c] : 0.0f;
+                    }
+                }
                 uint16_t o[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const int c = min(co + e, p.Cout - 1);
-                    float x = v[e] * (p.scale ? p.scale[c] : 1.0f) + (p.bias ? p.bias[c] : 0.0f);
+                    float x = v[e] * sc[e] + bi[e];
                     if (p.res) {
-                        const uint16_t rb = nco == 8 ? (uint16_t)((e & 1) ? rres[e >> 1] >> 16 : rres[e >> 1] & 0xffffu) : p.res[(size_t)m * p.res_ld + c];
+                        const uint16_t rb = nco == 8 ? (uint16_t)((e & 1) ? rres[e >> 1] >> 16 : rres[e >> 1] & 0xffffu) : p.res[(size_t)m * p.res_ld + min(co + e, p.Cout - 1)];
                         x += arseg_h2f<BF>(rb);
                     }
                     o[e] = arseg_f2h<BF>(act_apply(x, p.act, p.slope));
@@ -209,14 +225,19 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     }
 }
 
-template <bool BF, int CO_T>
+template <bool BF, int CO_T, int BK>
 int launch(const Conv16Params &p, hipStream_t st) {
-    const size_t stage = (size_t)2 * (CO_T + PIX_T) * LDK * 2, epi = (size_t)(CO_T == 128 ? 64 : 128) * (CO_T + 4) * 4;
+    const size_t stage = (size_t)2 * (CO_T + PIX_T) * (BK + 8) * 2, epi = (size_t)(CO_T == 128 ? 64 : 128) * (CO_T + 4) * 4;
     const size_t smem = stage > epi ? stage : epi;
     static ArsegSmemAttr attr;
-    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_kernel<BF, CO_T>), smem)) return e;
-    hipLaunchKernelGGL((conv16_kernel<BF, CO_T>), dim3(p.tiles_co * p.tiles_px), dim3(256), smem, st, p);
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_kernel<BF, CO_T, BK>), smem)) return e;
+    hipLaunchKernelGGL((conv16_kernel<BF, CO_T, BK>), dim3(p.tiles_co * p.tiles_px), dim3(256), smem, st, p);
     return arseg_launch_status();
+}
+template <bool BF>
+int launch_cfg(const Conv16Params &p, bool wide, bool deep, hipStream_t st) {
+    if (wide) return deep ? launch<BF, 128, 64>(p, st) : launch<BF, 128, 32>(p, st);
+    return deep ? launch<BF, 64, 64>(p, st) : launch<BF, 64, 32>(p, st);
 }
 
 }  // namespace
@@ -239,15 +260,22 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     p.out = (uint16_t *)out;
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout; p.out_ld = d->out_ld;
     p.res_ld = d->res_ld; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
-    p.K = d->R * d->S * d->Cin; p.Kpad = (p.K + BK - 1) / BK * BK; p.act = d->act; p.slope = d->prelu_slope;
+    p.K = d->R * d->S * d->Cin; p.Kpad = (p.K + KPAD - 1) / KPAD * KPAD; p.act = d->act; p.slope = d->prelu_slope;
     const long long M = (long long)d->N * Ho * Wo;
     const size_t in_bytes = (size_t)d->N * d->H * d->W * d->in_ld * 2, w_bytes = (size_t)d->Cout * p.Kpad * 2;
     if (M >= (1ll << 31) || in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return ARSEG_EUNSUPPORTED;       // 32-bit buffer offsets
     p.M = (int)M; p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
-    const bool wide = d->tile_cfg == 2 || (d->tile_cfg == 0 && d->Cout > 64);
+    // tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with K step 64
+    const int cfg = d->tile_cfg;
+    if (cfg < 0 || cfg > 4) return ARSEG_EINVAL;
+    bool wide = cfg == 2 || cfg == 4, deep = cfg >= 3;
+    if (cfg == 0) {
+        // 128-channel tiles when they still give every CU a few workgroups, K step 64 (half the barriers, 74 KB of LDS) for long K loops
+        wide = d->Cout > 64 && (long long)arseg_cdiv(d->Cout, 128) * arseg_cdiv(M, PIX_T) >= 512;
+        deep = p.K >= 512;
+    }
     const int co_t = wide ? 128 : 64;
     p.tiles_co = arseg_cdiv(d->Cout, co_t); p.tiles_px = arseg_cdiv(M, PIX_T);
     hipStream_t st = arseg_stream(stream);
-    if (dtype == ARSEG_DT_BF16) return wide ? launch<true, 128>(p, st) : launch<true, 64>(p, st);
-    return wide ? launch<false, 128>(p, st) : launch<false, 64>(p, st);
+    return dtype == ARSEG_DT_BF16 ? launch_cfg<true>(p, wide, deep, st) : launch_cfg<false>(p, wide, deep, st);
 }

@@ -172,6 +172,33 @@ __global__ __launch_bounds__(256) void resize_nchw_kernel(const float *__restric
     }
 }
 
+// Bilinear NCHW resize, 4 consecutive x outputs per thread (one 16-byte store; the row taps and the y blend are shared): the
+// x8 / x16 upsamples of BiSeNetOutput (model/bisenet.py:215-216) write 0.4 GB of logits per 11-frame batch and are store bound.
+__global__ __launch_bounds__(256) void resize_nchw_bilinear_x4_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin, int Win,
+                                                                      int Hout, int Wout, int align) {
+    const int w4 = Wout >> 2;
+    const long long total = (long long)NC * Hout * w4;
+    const float sy = arseg_resize_scale(Hin, Hout, align), sx = arseg_resize_scale(Win, Wout, align);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int xq = (int)(idx % w4), oy = (int)((idx / w4) % Hout);
+        const long long pc = idx / ((long long)w4 * Hout);
+        const float *base = in + (size_t)pc * Hin * Win;
+        int y0, y1; float ly;
+        arseg_src_index(sy, oy, align, Hin, y0, y1, ly);
+        ly = fminf(fmaxf(ly, 0.f), 1.f);
+        const float *r0 = base + (size_t)y0 * Win, *r1 = base + (size_t)y1 * Win;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int x0, x1; float lx;
+            arseg_src_index(sx, 4 * xq + e, align, Win, x0, x1, lx);
+            lx = fminf(fmaxf(lx, 0.f), 1.f);
+            v[e] = (1.f - ly) * ((1.f - lx) * r0[x0] + lx * r0[x1]) + ly * ((1.f - lx) * r1[x0] + lx * r1[x1]);
+        }
+        *reinterpret_cast<f32x4 *>(out + ((size_t)pc * Hout + oy) * Wout + 4 * xq) = v;
+    }
+}
+
 // ------------------------------------------------------------------ pyramid priors: sum of bilinear upsamples
 // out[n,y,x,c] = sum_s bilinear(align_corners=False)( t[n, off_s .. off_s + size_s^2, c] reshaped [size_s,size_s] )(y,x)
 struct PriorSizes { int n; int size[4]; int off[4]; int rows; };
@@ -502,8 +529,12 @@ extern "C" int arseg_resize_fwd(const float *in, float *out, int N, int C, int H
         hipLaunchKernelGGL(resize_nhwc_kernel, dim3(grid_for((long long)N * Hout * Wout * (C >> 2))), dim3(256), 0,
                            arseg_stream(stream), in, out, N, C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0, in_ld, out_ld);
     } else if (layout == ARSEG_NCHW) {
-        hipLaunchKernelGGL(resize_nchw_kernel, dim3(grid_for((long long)N * C * Hout * Wout, 16384)), dim3(256), 0,
-                           arseg_stream(stream), in, out, N * C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0);
+        if (mode == ARSEG_BILINEAR && (Wout & 3) == 0 && ARSEG_ALIGNED16(out))
+            hipLaunchKernelGGL(resize_nchw_bilinear_x4_kernel, dim3(grid_for((long long)N * C * Hout * (Wout >> 2), 16384)), dim3(256), 0,
+                               arseg_stream(stream), in, out, N * C, Hin, Win, Hout, Wout, align_corners ? 1 : 0);
+        else
+            hipLaunchKernelGGL(resize_nchw_kernel, dim3(grid_for((long long)N * C * Hout * Wout, 16384)), dim3(256), 0,
+                               arseg_stream(stream), in, out, N * C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0);
     } else return ARSEG_EINVAL;
     return arseg_launch_status();
 }

@@ -86,16 +86,17 @@ __global__ __launch_bounds__(256) void maxpool16_kernel(const uint16_t *__restri
     }
 }
 
-// ------------------------------------------------------------------ torch.mean(x, (2,3)): one workgroup per (image, 8-channel vector block of 32)
+// ------------------------------------------------------------------ torch.mean(x, (2,3)) in two steps: fp32 partial sums of pixel slices, then the mean
+// step 1: grid (C/256 blocks of 32 channel vectors, N, S slices); block = 32 channel vectors x 8 pixel lanes; part[n][s][c] fp32
 template <bool BF>
-__global__ __launch_bounds__(256) void global_mean16_kernel(const uint16_t *__restrict__ in, int in_ld, uint16_t *__restrict__ out, int HW, int C) {
-    // block = 32 channel vectors (256 channels) x 8 pixel lanes
+__global__ __launch_bounds__(256) void global_sum16_kernel(const uint16_t *__restrict__ in, int in_ld, float *__restrict__ part, int HW, int C, int S) {
     __shared__ float red[8][32][8];
-    const int n = blockIdx.y, cv = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+    const int n = blockIdx.y, sl = blockIdx.z, cv = blockIdx.x * 32 + (threadIdx.x & 31), pl = threadIdx.x >> 5;
+    const int per = (HW + S - 1) / S, p0 = sl * per, p1 = min(p0 + per, HW);
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (cv * 8 < C) {
         const uint16_t *base = in + (size_t)n * HW * in_ld + cv * 8;
-        for (int px = pl; px < HW; px += 8) {
+        for (int px = p0 + pl; px < p1; px += 8) {
             float f[8];
             unpack8<BF>(ld8(base + (size_t)px * in_ld), f);
 #pragma unroll
@@ -106,16 +107,25 @@ __global__ __launch_bounds__(256) void global_mean16_kernel(const uint16_t *__re
     for (int e = 0; e < 8; ++e) red[pl][threadIdx.x & 31][e] = acc[e];
     __syncthreads();
     if (pl == 0 && cv * 8 < C) {
-        float s[8];
+        float *o = part + ((size_t)n * S + sl) * C + cv * 8;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31][e];
-            s[e] = t / (float)HW;
+            o[e] = t;
         }
-        st8(out + (size_t)n * C + cv * 8, pack8<BF>(s));
     }
+}
+// step 2: out[n][c] = sum_s part[n][s][c] / HW  (fixed order: deterministic)
+template <bool BF>
+__global__ __launch_bounds__(256) void global_mean_fin16_kernel(const float *__restrict__ part, uint16_t *__restrict__ out, int N, int C, int S, float inv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    float t = 0.f;
+    for (int s = 0; s < S; ++s) t += part[((size_t)n * S + s) * C + c];
+    out[i] = arseg_f2h<BF>(t * inv);
 }
 
 // ------------------------------------------------------------------ resize (nearest / bilinear, align_corners on / off)
@@ -320,12 +330,37 @@ extern "C" int arseg_maxpool3x3s2_16_fwd(const void *in, void *out, int dtype, i
     return arseg_launch_status();
 }
 
-extern "C" int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int dtype, int N, int H, int W, int C, arseg_stream_t stream) {
+static int mean16_slices(int N, int HW, int C) {
+    long long blocks = (long long)arseg_cdiv(C, 256) * N;
+    int S = (int)(1024 / (blocks < 1 ? 1 : blocks));          // aim for ~1024 workgroups
+    S = S < 1 ? 1 : S;
+    const int maxS = (HW + 63) / 64;                           // at least 64 pixels per slice
+    return S > maxS ? maxS : S;
+}
+
+extern "C" size_t arseg_global_mean16_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return (size_t)N * mean16_slices(N, H * W, C) * C * sizeof(float);
+}
+
+extern "C" int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int dtype, int N, int H, int W, int C, void *workspace,
+                                       size_t workspace_bytes, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
-    if ((C & 7) || (in_ld & 7) || in_ld < C || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out) || N > 65535) return ARSEG_EINVAL;
-    const dim3 grid(arseg_cdiv(C, 256), N);
-    DISPATCH_BF(dtype, hipLaunchKernelGGL(global_mean16_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)in, in_ld, (uint16_t *)out, H * W, C),
-                hipLaunchKernelGGL(global_mean16_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)in, in_ld, (uint16_t *)out, H * W, C));
+    if ((C & 7) || (in_ld & 7) || in_ld < C || !ARSEG_ALIGNED16(in) || N > 65535) return ARSEG_EINVAL;
+    const int S = mean16_slices(N, H * W, C);
+    if (!workspace || workspace_bytes < (size_t)N * S * C * sizeof(float)) return ARSEG_EWORKSPACE;
+    const dim3 grid(arseg_cdiv(C, 256), N, S);
+    float *part = (float *)workspace;
+    const int gf = arseg_cdiv((long long)N * C, 256);
+    hipStream_t st = arseg_stream(stream);
+    const float inv = 1.0f / (float)(H * W);
+    if (dtype == ARSEG_DT_BF16) {
+        hipLaunchKernelGGL(global_sum16_kernel<true>, grid, dim3(256), 0, st, (const uint16_t *)in, in_ld, part, H * W, C, S);
+        hipLaunchKernelGGL(global_mean_fin16_kernel<true>, dim3(gf), dim3(256), 0, st, part, (uint16_t *)out, N, C, S, inv);
+    } else if (dtype == ARSEG_DT_F16) {
+        hipLaunchKernelGGL(global_sum16_kernel<false>, grid, dim3(256), 0, st, (const uint16_t *)in, in_ld, part, H * W, C, S);
+        hipLaunchKernelGGL(global_mean_fin16_kernel<false>, dim3(gf), dim3(256), 0, st, part, (uint16_t *)out, N, C, S, inv);
+    } else return ARSEG_EINVAL;
     return arseg_launch_status();
 }
 

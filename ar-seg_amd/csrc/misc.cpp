@@ -43,7 +43,7 @@ static uint16_t f32_to_f16_rne(float f) {
     return (uint16_t)(sign | half);
 }
 
-extern "C" int arseg_packed_k16(int Cin_pad, int R, int S) { return (R * S * Cin_pad + 31) / 32 * 32; }
+extern "C" int arseg_packed_k16(int Cin_pad, int R, int S) { return (R * S * Cin_pad + 63) / 64 * 64; }
 
 extern "C" int arseg_pack_conv_weight16_host(const float *w, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host) {
     if (!w || !out_host || Cout <= 0 || Cin <= 0 || R <= 0 || S <= 0 || Cin_pad < Cin || (Cin_pad & 7)) return ARSEG_EINVAL;

@@ -736,7 +736,9 @@ def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
             raise _lib.ArsegError("16-bit path: only the mean reduction is built (BiSeNet ARM / FFM / conv_avg)")
         N, H, W, C = x.shape
         out = torch.empty((N, 1, 1, C), dtype=x.dtype, device=x.device)
-        _launch("global_reduce", _lib.load().arseg_global_mean16_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), dt, N, H, W, C, _stream())
+        nb = _lib.load().arseg_global_mean16_workspace_bytes(N, H, W, C)
+        ws = workspace(nb, x.device)
+        _launch("global_reduce", _lib.load().arseg_global_mean16_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), dt, N, H, W, C, _ptr(ws), nb, _stream())
         return out
     _need_gpu(x)
     N, H, W, C = x.shape

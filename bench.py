@@ -51,6 +51,12 @@ CONFIGS = {
                    label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.3x (307x614) + CReFF 7x7 @128x256 (BASELINE configs[4] shapes, fp32 tensors)"),
     "bise": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=60.6, ref_hr_gflop=242.8,
                  label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256"),
+    # BASELINE configs[2]: BiSeNet-18 LR 0.5x + CReFF, 1024x2048 keyframe / 512x1024 non-key, bf16 tensors
+    "bise_bf16": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=60.6, ref_hr_gflop=242.8, storage="bf16",
+                      label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.5x (512x1024) + CReFF 7x7 @128x256, bf16 activations and weights (BASELINE configs[2])"),
+    # BASELINE configs[4] on one GPU: BiSeNet-18 LR 0.3x (307x614) at 1024x2048, fp16 MFMA conv path
+    "bise03_fp16": dict(kind="bise", H=1024, W=2048, n_cls=19, C=256, feat_div=8, ref_lr_gflop=0.0, ref_hr_gflop=242.8, scale=0.3, storage="f16",
+                        label="BiSeNet-18 HR keyframe 1024x2048 + 11 non-keyframes LR 0.3x (307x614) + CReFF 7x7 @128x256, fp16 activations and weights (BASELINE configs[4] shapes)"),
 }
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
@@ -113,6 +119,11 @@ def main():
     H, W, N_CLS = cfg["H"], cfg["W"], cfg["n_cls"]
     mean, std = (synth.CAMVID_MEAN, synth.CAMVID_STD) if cfg["kind"] == "psp" else (synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)
     hr, lr, sd_hr, sd_lr = build_nets(dev, cfg)
+    storage = cfg.get("storage", "f32")
+    if storage != "f32":          # 16-bit storage path: one fp16 / bf16 MFMA per product, fp32 accumulation and epilogue
+        sdt = {"bf16": torch.bfloat16, "f16": torch.float16}[storage]
+        hr.set_storage(sdt)
+        lr.set_storage(sdt)
 
     # ---- synthetic batch: `world` GOPs; this rank owns keyframe `rank` and 11 round-robin non-keyframes
     def key_fn(key_img):
@@ -180,17 +191,19 @@ def main():
                    "psp2k": "non-keyframe frames/sec (backbone+CReFF), PSPNet-18 1024x2048 / LR 512x1024",
                    "semseg": "non-keyframe frames/sec (backbone+CReFF), Cityscapes PSPNet-18 1024x2048 / LR 512x1024",
                    "bise03": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614",
-                   "bise": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024"}[args.config],
+                   "bise": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024",
+                   "bise_bf16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024, bf16",
+                   "bise03_fp16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614, fp16"}[args.config],
         "value": nonkey_per_step * args.steps / elapsed,
         "unit": "frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16" if args.conv_math == "f16" else "f32", "data": "synthetic",
+        "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
         "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
                                        "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
         "streams": len(streams),
-        "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights, fp32 tensors",
+        "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
         "all_frames_per_s": world * GOP * args.steps / elapsed,
@@ -221,6 +234,8 @@ def main():
             sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9
         mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]
+        if storage != "f32":
+            mfma_mult, peak = 1.0, PEAK_F16_MFMA_TFLOPS
         gemm_tf = tot_flops / (tot_ms * 1e-3) / 1e12
         conv_traffic = None
         tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command (profiles/collect.sh)
@@ -231,7 +246,8 @@ def main():
             conv_traffic = traffic_db.get("conv_all_tiles", {}).get("hbm_bytes_per_launch")
         ref_tf = ref_flops / (tot_ms * 1e-3) / 1e12 if ref_flops else None
         result["roofline_conv"] = {
-            "kernel": "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / batched Winograd GEMM; " +
+            "kernel": ("conv16_kernel<BF,CO_T> (implicit GEMM on 16-bit NHWC tensors, one v_mfma_f32_32x32x16_" + ("bf16" if storage == "bf16" else "f16") + " per product)") if storage != "f32" else
+                      "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / batched Winograd GEMM; " +
                       {"f16x3": "3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)", "f16": "v_mfma_f32_32x32x16_f16 on fp16-rounded operands)",
                        "f32": "v_mfma_f32_32x32x2_f32)"}[args.conv_math],
             "bound": "mfma", "achieved": ref_tf, "peak": peak, "unit": "TFLOP/s",
@@ -252,7 +268,9 @@ def main():
         C, fd = cfg["C"], cfg["feat_div"]
         Hp, Wp = H // fd, W // fd
         logit_px = Hp * Wp if cfg["kind"] == "semseg" else H * W              # pspnet_semseg phase 2 returns logits at feature resolution
-        stage_bytes = 4 * C * Hp * Wp + 4 * C * (Hp // 2) * (Wp // 2) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
+        e_in = 2 if storage != "f32" else 4                                 # element size of ref_p / lr; p and the logits leave the CReFF kernel in fp32
+        hp_, wp_ = int(H * SCALE) // fd if cfg["kind"] != "psp" else H // 2, int(W * SCALE) // fd if cfg["kind"] != "psp" else W // 2
+        stage_bytes = e_in * C * Hp * Wp + e_in * C * max(hp_, 1) * max(wp_, 1) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
         nfr = len(runner.plan)
         nb = 3 * nfr                                                      # frames covered by the profiled launches
         zero = {"ms": 0.0, "flops": 0, "launches": 1}

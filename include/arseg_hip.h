@@ -269,7 +269,8 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  * v_mfma_f32_32x32x16_{f16,bf16}, accumulation and the epilogue (folded BN scale / bias, residual, activation) are fp32, results are
  * rounded to 16 bits once, at the store.  Cin % 8 == 0 (frames are ingested as NHWC8), in_ld / out_ld / res_ld % 8 == 0.
  *   arseg_pack_conv_weight16_host: OIHW fp32 -> [Cout][Kpad16] 16-bit with k = (r*S+s)*Cin_pad + ci, Kpad16 = arseg_packed_k16(...)
- *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto, 1 = 64-channel tile, 2 = 128-channel tile; split_k / batch unused)
+ *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with
+ *                       K step 64; split_k / batch unused)
  * ------------------------------------------------------------------------------------------- */
 int arseg_packed_k16(int Cin_pad, int R, int S);
 int arseg_pack_conv_weight16_host(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host);
@@ -283,7 +284,9 @@ int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, cons
  *   warp_mvq16: arseg_warp_mvq_fwd on a 16-bit keyframe feature, fp32 C8 out (the CReFF kernels' input layout) */
 int arseg_frame_to_nhwc8_16_fwd(const float *img, void *out, int dtype, int N, int H, int W, int h, int w, arseg_stream_t stream);
 int arseg_maxpool3x3s2_16_fwd(const void *in, void *out, int dtype, int N, int H, int W, int C, arseg_stream_t stream);
-int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int dtype, int N, int H, int W, int C, arseg_stream_t stream);
+size_t arseg_global_mean16_workspace_bytes(int N, int H, int W, int C);      /* fp32 partial sums of pixel slices */
+int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int dtype, int N, int H, int W, int C, void *workspace,
+                            size_t workspace_bytes, arseg_stream_t stream);
 int arseg_resize16_fwd(const void *in, void *out, int dtype, int N, int C, int Hin, int Win, int Hout, int Wout, int mode,
                        int align_corners, int in_ld, int out_ld, arseg_stream_t stream);
 int arseg_scale_add16_fwd(const void *x, const void *scale, const void *add_full, const void *add_vec, void *out, int dtype, int N,

@@ -83,9 +83,11 @@ def test_conv2d16(dev, case, dtype):
         r = rnd(7, *y.shape).to(dtype)
         y = y + r.double()
     y = {"none": lambda v: v, "relu": torch.relu, "prelu": lambda v: torch.where(v >= 0, v, 0.2 * v), "sigmoid": torch.sigmoid}[act](y)
-    got = ops.conv2d(xn.to(dev), pc, residual=None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev))
-    assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
-    close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+    rd = None if r is None else r.permute(0, 2, 3, 1).contiguous().to(dev)
+    for cfg in (0, 1, 2, 3, 4):             # automatic choice, then every tile shape (64 / 128 channels x K step 32 / 64)
+        got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg)
+        assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
+        close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
