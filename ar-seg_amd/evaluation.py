@@ -154,6 +154,20 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
     return lr_net.phase2_warp(feat, list(ref_ps), mv_qs)               # a2 + a1 (each frame has its own MV map) + CReFF + head
 
 
+def alter_res_phase1(lr_net, imgs, scale=0.5):
+    """First half of ``alter_res_batch_fast``: frame downscale + ingest + LR backbone (evaluation.py:186-191).  Independent of the
+    keyframe feature -- the multi-GPU runner overlaps it with the exchange of ``ref_p`` (arseg_amd/gop.py)."""
+    lr_net = _unwrap(lr_net)
+    B, _, H, W = imgs.shape
+    h, w = _downscale_hw(H, W, scale)
+    return lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype))[-1]
+
+
+def alter_res_phase2(lr_net, feat, ref_ps, mv_qs):
+    """Second half: MV resize + warp + CReFF + head on the phase-1 feature (evaluation.py:176-183,193) -> logits."""
+    return _unwrap(lr_net).phase2_warp(feat, list(ref_ps), mv_qs)[0]
+
+
 def alter_res_batch_pred(lr_net, ref_ps, imgs, mv_qs, scale=0.5, labels=None, hist=None, ignore_label=255):
     """B non-keyframes through backbone + warp + CReFF + head and the evaluator tail (evaluation.py:201-209) in one go:
     -> (pred int32 [B,H,W], hist int64 [n_cls,n_cls] | None).  For BiSeNet the head's 1/8-resolution logits go straight into

@@ -2,22 +2,31 @@
 
 The reference has no multi-GPU inference path (``nn.DataParallel`` is bypassed on the hot path,
 evaluation.py:190-193, and evaluation runs batch 1); this is the design ``BASELINE.json: north_star``
-mandates on top of it:
+mandates on top of it.  Two plans, both with ONE exchange step over RCCL/xGMI
+(``torch.distributed`` backend "nccl") and nothing else on the data path:
 
-* a batch is ``world`` GOPs; rank ``g`` owns keyframe ``g`` and runs the HR forward for it;
-* ONE exchange step: an all-gather of the (un-warped) keyframe features ``ref_p`` over RCCL/xGMI
-  (``torch.distributed`` backend "nccl"); each non-keyframe needs only its own pixels, its own
-  accumulated MV map and its GOP's ``ref_p`` -- no frame-to-frame recurrence (evaluation.py:161-193);
-* the ``world * (gop-1)`` non-keyframes are dealt round-robin (``frame f -> rank f % world``), so every
-  rank processes ``gop-1`` of them; outputs stay rank-local; only the confusion matrix is all-reduced
-  (the reference's dormant ``dist.all_reduce(hist)``, evaluation.py:134-135).
+* **batched GOPs** (``n_gops`` a multiple of the world size; BASELINE configs[3]): rank ``g`` owns keyframe ``g`` and runs
+  the HR forward for it; one all-gather of the (un-warped) keyframe features ``ref_p``; the
+  ``n_gops * (gop-1)`` non-keyframes are dealt round-robin (``frame f -> rank f % world``), ``gop-1`` per rank per GOP;
+* **single GOP** (``n_gops == 1`` with ``world > 1``; the literal reading of the north star): the owner (rank 0) runs the
+  HR forward and broadcasts ``ref_p``; the ``gop-1`` non-keyframes are dealt round-robin over the ranks (11 frames over 8
+  ranks: 2 + 1, the imbalance SURVEY.md section 8e notes).
 
-The runner is generic over the two per-frame functions so that the sharding / exchange logic is testable
-on CPU with the gloo backend (tests/test_gop_runner.py); bench.py and the GPU tests plug in the HIP path.
+Each non-keyframe needs only its own pixels, its own accumulated MV map and its GOP's ``ref_p`` -- no
+frame-to-frame recurrence (evaluation.py:161-193).  Outputs stay rank-local; only the confusion matrix
+is all-reduced (the reference's dormant ``dist.all_reduce(hist)``, evaluation.py:134-135).
+
+Overlap: the LR backbone (phase 1) of a rank's non-keyframes does not depend on ``ref_p``.  ``run_overlapped`` therefore
+enqueues the exchange on a side stream right after the HR forward, runs phase 1 of the whole local batch on the main
+stream while the collective is in flight, and joins the streams only in front of phase 2 (warp + CReFF).  The
+gather buffer is allocated once per shape and reused.
+
+The runner is generic over the per-frame functions so that the sharding / exchange logic is testable on
+CPU with the gloo backend (tests/test_gop_runner.py); bench.py and the GPU tests plug in the HIP path.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -51,35 +60,83 @@ class GopRunner:
         self.n_gops, self.gop, self.group = n_gops, gop, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
-        if n_gops % self.world:
+        self.single_gop = n_gops < self.world
+        if self.single_gop and n_gops != 1:
+            raise ValueError(f"n_gops ({n_gops}) must be 1 (single-GOP plan) or a multiple of the world size ({self.world})")
+        if not self.single_gop and n_gops % self.world:
             raise ValueError(f"n_gops ({n_gops}) must be a multiple of the world size ({self.world})")
         self.plan = frame_plan(n_gops, gop, self.world)[self.rank]
         self.my_gops = [g for g in range(n_gops) if keyframe_owner(g, self.world) == self.rank]
+        self._gather_buf: Optional[torch.Tensor] = None          # reused across steps (1 GB at world 8 for the PSPNet feature)
+        self._side_stream = None
 
-    def exchange(self, local_refs: Sequence[torch.Tensor]) -> List[torch.Tensor]:
-        """All-gather of the keyframe features: returns ref_p for every GOP, indexed by gop."""
-        if self.world == 1:
-            return list(local_refs)
-        per_rank = len(local_refs)
-        stacked = torch.stack(list(local_refs)) if per_rank > 1 else local_refs[0].unsqueeze(0)
-        flat = torch.empty((self.world * per_rank,) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
-        dist.all_gather_into_tensor(flat, stacked.contiguous(), group=self.group)        # concatenation along dim 0
-        gathered = flat.view((self.world, per_rank) + tuple(stacked.shape[1:]))
-        refs = [None] * self.n_gops
+    # ------------------------------------------------------------------ the exchange step
+    def _buffer(self, stacked: torch.Tensor) -> torch.Tensor:
+        shape = (self.world * stacked.shape[0],) + tuple(stacked.shape[1:])
+        b = self._gather_buf
+        if b is None or tuple(b.shape) != shape or b.dtype != stacked.dtype or b.device != stacked.device:
+            b = self._gather_buf = torch.empty(shape, dtype=stacked.dtype, device=stacked.device)
+        return b
+
+    def _index(self, gathered: torch.Tensor, per_rank: int) -> List[torch.Tensor]:
+        refs: List[Optional[torch.Tensor]] = [None] * self.n_gops
         for r in range(self.world):
             owned = [g for g in range(self.n_gops) if keyframe_owner(g, self.world) == r]
             for i, g in enumerate(owned):
                 refs[g] = gathered[r, i]
         return refs
 
-    def run(self, keyframes, frames, mvs):
+    def exchange(self, local_refs: Sequence[torch.Tensor], like: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """Keyframe features for every GOP, indexed by gop.  Batched plan: one all-gather; single-GOP plan: one broadcast from
+        the owner (``like``: a tensor with the feature's shape / dtype / device for the ranks that own no keyframe)."""
+        if self.world == 1:
+            return list(local_refs)
+        if self.single_gop:
+            if self.rank == 0:
+                buf = local_refs[0].contiguous()
+            else:
+                if like is None:
+                    raise ValueError("single-GOP plan: ranks without the keyframe need `like` (shape / dtype / device of ref_p)")
+                buf = self._buffer(like.unsqueeze(0))[0]
+            dist.broadcast(buf, src=0, group=self.group)
+            return [buf]
+        per_rank = len(local_refs)
+        stacked = torch.stack(list(local_refs)) if per_rank > 1 else local_refs[0].unsqueeze(0)
+        flat = self._buffer(stacked)
+        dist.all_gather_into_tensor(flat, stacked.contiguous(), group=self.group)        # concatenation along dim 0
+        return self._index(flat.view((self.world, per_rank) + tuple(stacked.shape[1:])), per_rank)
+
+    # ------------------------------------------------------------------ schedules
+    def run(self, keyframes, frames, mvs, like: Optional[torch.Tensor] = None):
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
-        refs = self.exchange(local_refs)
+        refs = self.exchange(local_refs, like)
         return {(g, d): self.nonkey_fn(refs[g], frames[(g, d)], mvs[(g, d)]) for (g, d) in self.plan}
 
-    def run_batched(self, keyframes, frames_stacked, mvs_stacked, batch_fn):
+    def run_batched(self, keyframes, frames_stacked, mvs_stacked, batch_fn, like: Optional[torch.Tensor] = None):
         """Same schedule with this rank's non-keyframes processed as ONE batch: ``frames_stacked`` / ``mvs_stacked`` hold
         the frames of ``self.plan`` in plan order along dim 0; ``batch_fn(refs_per_frame, frames, mvs)`` -> outputs."""
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
-        refs = self.exchange(local_refs)
+        refs = self.exchange(local_refs, like)
         return batch_fn([refs[g] for (g, _) in self.plan], frames_stacked, mvs_stacked)
+
+    def run_overlapped(self, keyframes, frames_stacked, mvs_stacked, phase1_fn, phase2_fn, like: Optional[torch.Tensor] = None):
+        """HR forward -> exchange (side stream) || ``phase1_fn(frames)`` (main stream) -> join -> ``phase2_fn(feat, refs_per_frame,
+        mvs)``.  Phase 1 (frame downscale + LR backbone) does not read ``ref_p``, so the collective's latency hides behind it.  On
+        CPU tensors (gloo tests) the exchange simply runs first; the result is identical."""
+        local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
+        on_gpu = frames_stacked.is_cuda and self.world > 1
+        if on_gpu:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=frames_stacked.device)
+            main = torch.cuda.current_stream()
+            self._side_stream.wait_stream(main)                     # the HR forward has produced local_refs
+            with torch.cuda.stream(self._side_stream):
+                refs = self.exchange(local_refs, like)
+            feat = phase1_fn(frames_stacked)                        # overlaps the collective
+            main.wait_stream(self._side_stream)
+            for r in refs:
+                r.record_stream(main)
+        else:
+            refs = self.exchange(local_refs, like)
+            feat = phase1_fn(frames_stacked)
+        return phase2_fn(feat, [refs[g] for (g, _) in self.plan], mvs_stacked)

@@ -154,6 +154,10 @@ def main():
 
     def step():
         with torch.no_grad():
+            if world > 1 and not fused_tail:
+                # the exchange of the keyframe features runs on a side stream while the LR backbone (which does not read them) proceeds
+                return runner.run_overlapped(keyframes, frames_b, mvs_b, lambda f: ev.alter_res_phase1(lr, f, SCALE),
+                                             lambda feat, refs, mvq: ev.alter_res_phase2(lr, feat, refs, mvq))
             return runner.run_batched(keyframes, frames_b, mvs_b, batch_fn)
 
     # Consecutive GOPs are independent: rotating them over a few HIP streams lets the MFMA-bound backbone convs of one GOP

@@ -36,12 +36,28 @@ def _data(n_gops, gop=12):
     return keys, frames, mvs
 
 
-def _worker(rank, world, port, q):
+def _phase1(frames):
+    return frames * 2.0                  # (exactly invertible in floating point)
+
+
+def _phase2(feat, refs, mvs):
+    return torch.stack([_nonkey_fn(r, f / 2.0, m) for r, f, m in zip(refs, feat, mvs)])
+
+
+def _worker(rank, world, port, q, mode="batched"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    keys, frames, mvs = _data(world)
-    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=world)
-    out = runner.run({g: keys[g] for g in runner.my_gops}, {f: frames[f] for f in runner.plan}, {f: mvs[f] for f in runner.plan})
+    n_gops = 1 if mode == "single" else world
+    keys, frames, mvs = _data(n_gops)
+    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops)
+    like = torch.empty(3, 8, 8)
+    if mode == "overlapped":        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
+        fs = torch.stack([frames[f] for f in runner.plan])
+        ms = torch.stack([mvs[f] for f in runner.plan])
+        res = runner.run_overlapped({g: keys[g] for g in runner.my_gops}, fs, ms, _phase1, _phase2)
+        out = {f: res[i] for i, f in enumerate(runner.plan)}
+    else:
+        out = runner.run({g: keys[g] for g in runner.my_gops}, {f: frames[f] for f in runner.plan}, {f: mvs[f] for f in runner.plan}, like=like)
     hist = torch.tensor([float(len(out))])
     dist.all_reduce(hist)                                            # the confusion-matrix reduction pattern
     q.put((rank, {k: v.clone() for k, v in out.items()}, float(hist)))
@@ -49,7 +65,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_matches_single_process():
+import pytest
+
+
+@pytest.mark.parametrize("mode", ["batched", "overlapped", "single"])
+def test_two_rank_gloo_matches_single_process(mode):
+    """world 2 over gloo == the single-process run, bit for bit: the batched plan (all-gather), the overlapped schedule (exchange
+    concurrent with phase 1) and the single-GOP plan (owner broadcasts ref_p, 11 frames dealt over the ranks)."""
     world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -57,19 +79,23 @@ def test_two_rank_gloo_matches_single_process():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=120) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    keys, frames, mvs = _data(world)
-    single = GopRunner(_key_fn, _nonkey_fn, n_gops=world).run(keys, frames, mvs)     # no process group -> world 1
+    n_gops = 1 if mode == "single" else world
+    keys, frames, mvs = _data(n_gops)
+    single = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops).run(keys, frames, mvs)     # no process group -> world 1
     merged = {}
     for _, out, total in results:
-        assert total == world * 11
+        assert total == n_gops * 11
         merged.update(out)
+    if mode == "single":
+        sizes = sorted(len(out) for _, out, _ in results)
+        assert sizes == [5, 6]                                       # 11 frames over 2 ranks
     assert set(merged) == set(single)
     for k in single:
         assert torch.equal(merged[k], single[k])

@@ -397,3 +397,90 @@ def test_eval_alter_res_keyframe_cache(dev, manifest):
         m1 = cached(hr, lr, samples, 12)
     assert m0 == m1
     assert plain.hr_forwards == 3 and cached.hr_forwards == 1
+
+
+def _nccl_worker(rank, world, port, q, mode):
+    import os as _os
+
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.gop import GopRunner
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    H, W = 64, 96
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    n_gops = 1 if mode == "single" else world
+    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12)
+    clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
+    keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
+    fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner.plan]).to(dev)
+    mb = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in runner.plan]).to(dev)
+    like = torch.empty((H, W, 64), dtype=torch.float32, device=dev)
+    with torch.no_grad():
+        out = runner.run_overlapped(keyframes, fb, mb, lambda f: ev.alter_res_phase1(lr, f, 0.5),
+                                    lambda feat, refs, mvq: ev.alter_res_phase2(lr, feat, refs, mvq), like=like)
+        hist = torch.tensor([float(out.shape[0])], device=dev)
+        dist.all_reduce(hist)                                        # the confusion-matrix reduction (evaluation.py:134-135) on RCCL
+    torch.cuda.synchronize()
+    q.put((rank, list(runner.plan), out.cpu(), float(hist)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["batched", "single"])
+def test_two_rank_rccl_matches_single_process(dev, mode):
+    """The N-rank HIP path over RCCL (backend "nccl") equals the 1-rank path bit for bit: 2 ranks, the all-gather plan with the
+    exchange overlapped with phase 1, and the single-GOP broadcast plan.  Needs two GPUs (skipped on a 1-GPU box)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-process reference on this process' GPU
+    H, W = 64, 96
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    n_gops = 1 if mode == "single" else world
+    total = 0
+    for rank, plan, out, hist in results:
+        assert hist == n_gops * 11
+        total += len(plan)
+        for i, (g, d) in enumerate(plan):
+            clip = synth.make_clip(g, H, W, gop=12)
+            with torch.no_grad():
+                ref = ops.to_nhwc(hr(torch.from_numpy(clip["frames"][0:1]).to(dev))[-1])
+                want, _ = ev.alter_res_step_fast(lr, ref, torch.from_numpy(clip["frames"][d:d + 1]).to(dev), torch.from_numpy(clip["mv"][d:d + 1]).to(dev), 0.5)
+            assert torch.equal(out[i:i + 1], want.cpu()), (rank, g, d)
+    assert total == n_gops * 11
