@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured HIP graph (N = 1 only)")
     ap.add_argument("--conv-math", choices=["f16x3", "f32", "f16"], default="f16x3",
                     help="MFMA back end of the fp32 conv GEMMs: f16x3 = split-fp16 emulation (3 fp16 MFMAs, fp32 accumulate), f32 = fp32 MFMA")
     args = ap.parse_args()
@@ -164,12 +165,28 @@ def main():
     # run beside the VALU/LDS-bound warp + CReFF kernels of another.  Every step is fully executed; the timed region is
     # closed by a device-wide synchronize.
     streams = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.streams))]
+    # N = 1: the steps are captured once into a HIP graph (arseg_amd/executor.py: `streams` independent GOP steps on forked streams
+    # per replay, static memory) and replayed; K steps = K // lanes replays + K % lanes eager steps.  N > 1 runs eagerly (the
+    # exchange is an RCCL collective on a side stream).
+    gop_graph = None
+    if world == 1 and not args.no_graph:
+        from arseg_amd.executor import GopGraph
+        with torch.cuda.stream(streams[0]):
+            gop_graph = GopGraph([step] * len(streams), warmup=1)
+        torch.cuda.synchronize()
 
     def run_steps(k):
         out = None
-        for i in range(k):
+        i = 0
+        if gop_graph is not None:
+            with torch.cuda.stream(streams[0]):
+                while i + gop_graph.lanes <= k:
+                    out = gop_graph.replay()[0]
+                    i += gop_graph.lanes
+        while i < k:
             with torch.cuda.stream(streams[i % len(streams)]):
                 out = step()
+            i += 1
         return out
 
     run_steps(args.warmup)
@@ -206,7 +223,7 @@ def main():
         "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
         "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
                                        "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
-        "streams": len(streams),
+        "streams": len(streams), "executor": "hip-graph replay (%d GOP steps per replay on forked streams)" % len(streams) if gop_graph is not None else "eager launches",
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
