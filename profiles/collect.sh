@@ -11,7 +11,7 @@ mkdir -p $OUT
 export ARSEG_CONV_PLAN_FILE=$OUT/${TAG}_plans.json
 rm -f $ARSEG_CONV_PLAN_FILE
 cd $R
-python bench.py --steps 8 --warmup 3 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
+python bench.py --steps 9 --warmup 3 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o s --output-format csv -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
