@@ -87,6 +87,22 @@ __device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, const f32x4 
 // Record index (row-major in the 22 x 22 record region) of flat window key f = 16b + k0 (k0 in 0..15) of the patch at (pc, pr).
 // The window is 8 rows x 14 columns: f = 14 ky + kx.  With e = 2b + k0 (< 28): ky = b + (e >= 14), kx = e - 14 (e >= 14), so
 // rec = (2pr + ky) * 22 + 8pc + kx = [44 pr + 8 pc + k0] + 24 b + 8 (k0 >= 14 - 2b): one compare-select per block.
+// reductions over the 4 DPP rows of a wave (lanes l, l^16, l^32, l^48) on the VALU: v_permlane16_swap exchanges the odd rows of its
+// first operand with the even rows of the second, v_permlane32_swap the upper half of the first with the lower half of the second --
+// fed two copies of x they return the pair (x, partner's x) in every lane.  (__shfl_xor is a ds_bpermute: an LDS round trip that all
+// 16 lock-stepped waves of the workgroup wait for.)
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ int key_rec(int b, int k0, int base0) { return base0 + 24 * b + (k0 >= 14 - 2 * b ? 8 : 0); }
 
 #ifdef RR_TIMING
@@ -112,6 +128,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     unsigned *TapO = reinterpret_cast<unsigned *>(smem + TAPO_OFF);
     f32x4 *Wfs = reinterpret_cast<f32x4 *>(smem + WFS_OFF);        // [4 chunks][4 groups][NBA*16] {4 hi | 4 lo}
     f32x4 *WdQ = reinterpret_cast<f32x4 *>(smem + WDQ_OFF);
+    float *Bfs = reinterpret_cast<float *>(smem + WFS_OFF + 4 * 4 * NBA * 16 * 16);      // [NBA*16] classifier bias (0 beyond n_cls)
 
     const int tid0 = threadIdx.x;
     // Persistent workgroups (one per CU: 158 KB of LDS): each walks its share of the tiles, so the 16-wave launch latency is paid
@@ -205,6 +222,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             }
             TapW[t] = w; TapO[t] = o;
         }
+        RR_STAMP(9);
         if (RR_ON(2)) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) lr_commit(k, va[k], lya[k], lxa[k], ina[k]);
@@ -371,6 +389,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             }
         }
             // softmax over the 49 taps (padding taps included)
+        RR_STAMP(10);
         float m = -INFINITY;
 #pragma unroll
         for (int b = 0; b < 7; ++b)
@@ -379,8 +398,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                 S[b][i] = (okmask >> (4 * b + i)) & 1u ? S[b][i] : -INFINITY;
                 m = fmaxf(m, S[b][i]);
             }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        m = rows_max(m);
         const float ml = m * LOG2E;
         float z = 0.f;
 #pragma unroll
@@ -394,8 +412,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             split4(S[b], hi, lo);
             P[b] = u32x4{hi.x, hi.y, lo.x, lo.y};
         }
-        z += __shfl_xor(z, 16);
-        z += __shfl_xor(z, 32);
+        z = rows_sum(z);
         inv = 1.0f / z;                            // applied to the weighted sum instead of the 112 weights
 #pragma unroll
         for (int b = 0; b < 7; ++b) asm volatile("" : "+v"(P[b]));      // finish the softmax here, not behind the value conv
@@ -416,6 +433,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             split4(wv4, hi, lo);
             Wfs[t] = __builtin_bit_cast(f32x4, u32x4{hi.x, hi.y, lo.x, lo.y});
         }
+        if (NB > 0 && t >= 512 && t < 512 + NBA * 16) Bfs[t - 512] = t - 512 < p.n_cls ? p.bf[t - 512] : 0.f;
     }
     __syncthreads();
     RR_STAMP(7);
@@ -484,6 +502,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         }
 
         // logits: lg[nb][i] = class 16nb + 4g + i of query q
+        RR_STAMP(11);
         if (NB > 0) {
             const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
             float m = -INFINITY;
@@ -492,19 +511,17 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int cls = nb * 16 + 4 * g + i;
-                    lg[nb][i] += p.bf[min(cls, p.n_cls - 1)];
+                    lg[nb][i] += Bfs[cls];
                     m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
                 }
             if (p.log_softmax) {
-                m = fmaxf(m, __shfl_xor(m, 16));
-                m = fmaxf(m, __shfl_xor(m, 32));
+                m = rows_max(m);
                 float z = 0.f;
 #pragma unroll
                 for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? __expf(lg[nb][i] - m) : 0.f;
-                z += __shfl_xor(z, 16);
-                z += __shfl_xor(z, 32);
+                z = rows_sum(z);
                 const float lse = m + __logf(z);
 #pragma unroll
                 for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
