@@ -32,22 +32,29 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TX = 16, TY = 16, NT = 1024, CH = 64;
+constexpr int LW = 18, LN = 324, LPL = 329;          // lr_up tile (+1 halo) per channel group
 constexpr int R4W = 24, R4N = 576;                   // warped keyframe region: tile + 3 (window) + 1 (conv) halo
 constexpr int R3W = 22;                              // key / value records: tile + 3 halo (22 x 22 = 484 per channel group)
 constexpr int HPL = 577;                             // plane stride (float4) of the staged region: 577*4 % 32 == 4 -> the 8 lanes of a
                                                      // ds_write_b128 group (8 channel groups of one pixel) cover all 32 banks
 constexpr int KPLK = 496, KPLV = 500;                // record plane strides: keys (ds_read_b128) a multiple of 16 records, values
                                                      // (transpose read) 16 banks apart
-constexpr int LW = 18, LN = 324, LPL = 329;          // lr_up tile (+1 halo) per channel group
 constexpr int BIG_BYTES = 16 * HPL * 16;             // 147,712: staged region / lr_up tile / key records / value records
 constexpr int TAPW_OFF = BIG_BYTES;                  // [576] {ex, wx, ey, wy} with the tap validity folded in (0 = tap outside)
 constexpr int TAPO_OFF = TAPW_OFF + R4N * 16;        // [576] pixel index of the NW tap | dx << 30 | dy << 31 (clamped taps)
 constexpr int WFS_OFF = 16 * KPLV * 16;              // classifier records: behind the value records, inside BIG (128,000 + 8 KB <= 147,712)
 constexpr int WDQ_OFF = TAPO_OFF + R4N * 4;          // [4 chunks][9 taps + bias][4 groups] query conv weights
-constexpr int SMEM_BYTES = WDQ_OFF + 4 * 10 * 4 * 16;   // 161,792 <= 163,840
+constexpr int LRT_OFF = WDQ_OFF + 4 * 10 * 4 * 16;      // [18 rows | 18 columns] of the lr_up tile: {tap offset 0, tap offset 1, weight 0, weight 1}
+constexpr int SMEM_BYTES = LRT_OFF + 2 * LW * 16;       // 162,368 <= 163,840
 constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
+#ifndef RR_G1
+#define RR_G1 4       // gather units requested ahead of the query conv
+#endif
+#ifndef RR_GB
+#define RR_GB 5       // gather units per later batch
+#endif
 
 struct RRParams {
     const float *ref[MAXN];       // un-warped keyframe feature of each frame, NHWC [Hp][Wp][64]
@@ -69,6 +76,20 @@ __device__ __forceinline__ h16x8 pack8(const u32x2 a, const u32x2 b) { return __
 __device__ __forceinline__ u32x2 lds_tr16(const unsigned char *p) {
     return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)p));
 }
+// LDS[lds_base + lane * 16] <- 16 bytes at g (LDS-DMA: no staging registers).  Inline asm: hipcc serialises the builtin (waterfall loop
+// over M0 with a vmcnt(0) per load); the loads are invisible to its s_waitcnt bookkeeping, so the publishing barrier is preceded
+// by an explicit s_waitcnt vmcnt(0).
+__device__ __forceinline__ void dma16_glb(const void *g, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(g) : "memory");
+}
+__device__ __forceinline__ void dma4_glb(const void *g, unsigned lds_base) {        // LDS[lds_base + lane * 4] <- 4 bytes at g
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(g) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 template <int CTRL>
 __device__ __forceinline__ f32x4 dpp4(const f32x4 v) {     // row_shr:1 = 0x111 (lane i <- lane i-1), row_shl:1 = 0x101 (lane i <- lane i+1)
     f32x4 r;
@@ -128,6 +149,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     unsigned *TapO = reinterpret_cast<unsigned *>(smem + TAPO_OFF);
     f32x4 *Wfs = reinterpret_cast<f32x4 *>(smem + WFS_OFF);        // [4 chunks][4 groups][NBA*16] {4 hi | 4 lo}
     f32x4 *WdQ = reinterpret_cast<f32x4 *>(smem + WDQ_OFF);
+    u32x4 *LrT = reinterpret_cast<u32x4 *>(smem + LRT_OFF);
     float *Bfs = reinterpret_cast<float *>(smem + WFS_OFF + 4 * 4 * NBA * 16 * 16);      // [NBA*16] classifier bias (0 beyond n_cls)
 
     const int tid0 = threadIdx.x;
@@ -153,6 +175,19 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             if ((unsigned)(ky - qy) <= 6u && (unsigned)(kx - qx) <= 6u) okmask |= 1u << s;
         }
     }
+    // The motion vector of a lane's region pixel (lanes < 576; identity-resize case) is requested one tile ahead, by LDS-DMA into the
+    // lane's own slot of the tap-offset table (dead between the gather and the next tile's tap arithmetic): a register would be
+    // live across the whole tile and hipcc spills it (scratch traffic + a vmcnt(0) at the request).
+    const bool mv_ident = p.Hp == p.H && p.Wp == p.W;
+    auto mv_fetch = [&](int tile_) {
+        const int n_ = tile_ / per_img, tr_ = tile_ - n_ * per_img;
+        const int yr = tid0 / R4W, xr = tid0 - yr * R4W;
+        const int gy = (tr_ / p.tiles_x) * TY - 4 + yr, gx = (tr_ - (tr_ / p.tiles_x) * p.tiles_x) * TX - 4 + xr;
+        if (mv_ident && tid0 < R4N && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)
+            dma4_glb(p.mv + ((size_t)n_ * p.H * p.W + (size_t)gy * p.W + gx) * 2, lds_addr(TapO) + (unsigned)__builtin_amdgcn_readfirstlane(tid0 >> 6) * 256u);
+    };
+    if (t_lo + slot < t_hi) mv_fetch(t_lo + slot);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int tile = t_lo + slot; tile < t_hi; tile += nslot) {
     // Everything derived from the thread id is recomputed per phase from an opaque copy: left alone, LLVM hoists the per-lane
     // constants of all phases (record indices, masks, addresses) to the top of the tile loop where they occupy ~100 registers.
@@ -164,37 +199,40 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     const int ty0 = (trem / p.tiles_x) * TY, tx0 = (trem - (trem / p.tiles_x) * p.tiles_x) * TX;
     const int Hp = p.Hp, Wp = p.Wp;
 
-    // ------------------------------------------------------------------ phase 0: lr_up tile (+1 halo, all 64 channels) into LDS; sampling taps
-    // The tap arithmetic (fp64, one lane per region pixel) runs while the first batch of lr loads is in flight.
+    // ------------------------------------------------------------------ phase 0a: sampling taps; raw lr window under the tile into LDS
+    // The window of the low-resolution feature under the tile (+1 halo, +1 for the second bilinear tap; block uniform) is staged as
+    // whole 256-byte pixels (~110 coalesced pixel loads instead of 324 x 4 scattered 16-byte taps per channel group); the bilinear taps
+    // of the lr_up tile are then read from LDS.  The tap arithmetic of the warp (fp64, one lane per region pixel) runs while the
+    // window loads are in flight; the motion vector it starts from was requested during the previous tile.
+    int wy_lo, wx_lo, wy_n, wx_n;
+    {
+        int a0, a1, b0, b1; float l;
+        arseg_src_index(p.sy, max(ty0 - 1, 0), true, p.hp, a0, a1, l);
+        arseg_src_index(p.sy, min(ty0 + TY, Hp - 1), true, p.hp, b0, b1, l);
+        wy_lo = a0; wy_n = b1 - a0 + 1;
+        arseg_src_index(p.sx, max(tx0 - 1, 0), true, p.wp, a0, a1, l);
+        arseg_src_index(p.sx, min(tx0 + TX, Wp - 1), true, p.wp, b0, b1, l);
+        wx_lo = a0; wx_n = b1 - a0 + 1;
+    }
+    const int wnpx = wy_n * wx_n;
+    f32x4 *LwA = BIGf + 16 * LPL;                                             // [window pixel][16 channel groups], behind the lr_up tile
+    const bool win_lds = wnpx <= 256 && 16 * LPL * 16 + wnpx * 256 <= BIG_BYTES;      // (always at the 0.5x scale: <= 11 x 11 pixels)
     {
         RR_TID(t);
         const float *lrn = p.lr + (size_t)n * p.hp * p.wp * CH;
         const int g16 = t & 15, pl = t >> 4;
-        auto lr_issue = [&](int k, f32x4 (&v)[4], float &ly, float &lx, bool &inside) {
-            const int px = min(pl + 64 * k, LN - 1);
-            const int r = px / LW, c = px - r * LW;
-            const int gy = ty0 - 1 + r, gx = tx0 - 1 + c;
-            int y0, y1, x0, x1;
-            arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, y0, y1, ly);
-            arseg_src_index(p.sx, min(max(gx, 0), Wp - 1), true, p.wp, x0, x1, lx);
-            ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
-            inside = (unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp;
-            const float *b = lrn + g16 * 4;
-            v[0] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y0 * p.wp + x0) * CH);
-            v[1] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y0 * p.wp + x1) * CH);
-            v[2] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y1 * p.wp + x0) * CH);
-            v[3] = *reinterpret_cast<const f32x4 *>(b + (size_t)(y1 * p.wp + x1) * CH);
-        };
-        auto lr_commit = [&](int k, const f32x4 (&v)[4], float ly, float lx, bool inside) {
-            const int px = pl + 64 * k;
-            f32x4 o = (1.f - ly) * ((1.f - lx) * v[0] + lx * v[1]) + ly * ((1.f - lx) * v[2] + lx * v[3]);
-            if (!inside) o = f32x4{0.f, 0.f, 0.f, 0.f};           // conv zero padding outside the image
-            if (px < LN) BIGf[g16 * LPL + px] = o;
-        };
-        f32x4 va[3][4]; float lya[3], lxa[3]; bool ina[3];
-        if (RR_ON(2)) {
+        const unsigned mv_cur = t < R4N ? TapO[t] : 0u;
+        // window pixels by LDS-DMA: a wave's 64 lanes = 4 pixels x 16 channel groups = 1 KB contiguous in the pixel-major image
+        if (win_lds && RR_ON(2)) {
+            const unsigned wbase = lds_addr(LwA) + (unsigned)__builtin_amdgcn_readfirstlane(t >> 6) * 1024u;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lr_issue(k, va[k], lya[k], lxa[k], ina[k]);
+            for (int k = 0; k < 4; ++k) {
+                const int px = pl + 64 * k;
+                if (px < wnpx) {
+                    const int r = px / wx_n, c = px - r * wx_n;
+                    dma16_glb(lrn + ((size_t)(wy_lo + r) * p.wp + wx_lo + c) * CH + g16 * 4, wbase + k * 16384u);
+                }
+            }
         }
         if (!RR_ON(0)) {
             if (t < R4N) { TapW[t] = f32x4{0.5f, 0.5f, 0.5f, 0.5f}; TapO[t] = (unsigned)t; }
@@ -205,12 +243,10 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             unsigned o = 0;
             if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp) {      // outside the image the region is zero (conv padding)
                 double fx, fy;
-                const int16_t *mvn = p.mv + (size_t)n * p.H * p.W * 2;
-                if (Hp == p.H && Wp == p.W) {          // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
-                    const int16_t *m = mvn + ((size_t)gy * p.W + gx) * 2;
-                    fx = (double)m[0] / 4.0; fy = (double)m[1] / 4.0;
+                if (mv_ident) {                        // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
+                    fx = (double)(short)(mv_cur & 0xFFFFu) / 4.0; fy = (double)(short)(mv_cur >> 16) / 4.0;
                 } else {
-                    mv_at(mvn, p.H, p.W, Hp, Wp, gy, gx, fx, fy);
+                    mv_at(p.mv + (size_t)n * p.H * p.W * 2, p.H, p.W, Hp, Wp, gy, gx, fx, fy);
                 }
                 float ngx, ngy;
                 norm_grid<double>(gx, gy, fx, fy, Hp, Wp, ngx, ngy);
@@ -221,15 +257,87 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                 w = f32x4{tp.vx0 ? tp.ex : 0.f, tp.vx1 ? tp.wx : 0.f, tp.vy0 ? tp.ey : 0.f, tp.vy1 ? tp.wy : 0.f};
             }
             TapW[t] = w; TapO[t] = o;
+        } else if (t < R4N + 2 * LW) {
+            // bilinear (align_corners=True) taps of the lr_up tile, once per tile row / column: offsets relative to the staged window (or
+            // pixel offsets into the lr image without it); the zero padding outside the image is folded into the weights
+            const int i = t - R4N, isx = i >= LW, j = i - (isx ? LW : 0);
+            const int gq = (isx ? tx0 : ty0) - 1 + j, lim = isx ? Wp : Hp;
+            int i0, i1; float l;
+            arseg_src_index(isx ? p.sx : p.sy, min(max(gq, 0), lim - 1), true, isx ? p.wp : p.hp, i0, i1, l);
+            l = fminf(fmaxf(l, 0.f), 1.f);
+            const float in = (unsigned)gq < (unsigned)lim ? 1.f : 0.f;
+            const int mul = 16 * (isx ? 1 : (win_lds ? wx_n : p.wp)), lo = win_lds ? (isx ? wx_lo : wy_lo) : 0;     // in 16-byte units
+            LrT[i] = u32x4{(unsigned)((i0 - lo) * mul), (unsigned)((i1 - lo) * mul), __float_as_uint((1.f - l) * in), __float_as_uint(l * in)};
         }
-        RR_STAMP(9);
-        if (RR_ON(2)) {
+        RR_STAMP(12);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the window has landed (and the motion vector requested ahead of it)
+    }
+    __syncthreads();
+    RR_STAMP(9);
+
+    // ------------------------------------------------------------------ phases 1 + 2: query conv | gather + bilinear warp of the region into LDS
+    // Gather unit = (region pixel, channel group): 16 lanes read one whole 256-byte pixel per tap.  The staged region overwrites the
+    // lr_up tile, so it can only be WRITTEN after the query conv -- but the taps of the first G1 units are REQUESTED before it and
+    // travel while the conv runs (their 16 G1 registers are free here: neither the columns nor the softmax weights are live yet).
+    constexpr int G1 = RR_G1, GU = 9;
+    const float *g_img = p.ref[n];
+    const unsigned g_row_off = (unsigned)Wp * CH;
+    auto g_issue = [&](int k, f32x4 (&v)[4]) {
+        RR_TID(t);
+        const int g16 = t & 15, pix = (t >> 4) + 64 * k;
+        const unsigned o = TapO[pix];
+        const float *a = g_img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
+        const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? g_row_off : 0u;
+        v[0] = *reinterpret_cast<const f32x4 *>(a);
+        v[1] = *reinterpret_cast<const f32x4 *>(a + dxo);
+        v[2] = *reinterpret_cast<const f32x4 *>(a + dyo);
+        v[3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
+    };
+    auto g_commit = [&](int k, const f32x4 (&v)[4]) {
+        RR_TID(t);
+        const int g16 = t & 15, pix = (t >> 4) + 64 * k;
+        const f32x4 w = TapW[pix];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc += v[0] * (w[0] * w[2]);      // same order as warp_mvq_nhwc_kernel
+        acc += v[1] * (w[1] * w[2]);
+        acc += v[2] * (w[0] * w[3]);
+        acc += v[3] * (w[1] * w[3]);
+        BIGf[g16 * HPL + pix] = acc;
+    };
+    f32x4 gv[G1 > 0 ? G1 : 1][4];
+    if (RR_ON(1)) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lr_commit(k, va[k], lya[k], lxa[k], ina[k]);
+        for (int k = 0; k < G1; ++k) g_issue(k, gv[k]);
+    }
+
+    // ------------------------------------------------------------------ phase 0b: lr_up tile (+1 halo, all 64 channels) into LDS
+    if (RR_ON(2)) {
+        RR_TID(t);
+        const int g16 = t & 15, pl = t >> 4;
+        const f32x4 *lrg = reinterpret_cast<const f32x4 *>(p.lr + (size_t)n * p.hp * p.wp * CH) + g16;
+        const f32x4 *wb = LwA + g16;
+        // (two separate loops: with the LDS and the global taps merged into one, hipcc waits for vmcnt(0) -- i.e. for the gather
+        // requests in flight -- before every interpolation)
+        if (win_lds) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) lr_issue(3 + k, va[k], lya[k], lxa[k], ina[k]);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) lr_commit(3 + k, va[k], lya[k], lxa[k], ina[k]);
+            for (int k = 0; k < 6; ++k) {
+                const int px = pl + 64 * k;
+                if (k < 5 || px < LN) {
+                    const int r = px / LW, c = px - r * LW;
+                    const u32x4 rt = LrT[r], ct = LrT[LW + c];
+                    const float wy0 = __uint_as_float(rt.z), wy1 = __uint_as_float(rt.w), wx0 = __uint_as_float(ct.z), wx1 = __uint_as_float(ct.w);
+                    const f32x4 v0 = wb[rt.x + ct.x], v1 = wb[rt.x + ct.y], v2 = wb[rt.y + ct.x], v3 = wb[rt.y + ct.y];
+                    BIGf[g16 * LPL + px] = wy0 * (wx0 * v0 + wx1 * v1) + wy1 * (wx0 * v2 + wx1 * v3);
+                }
+            }
+        } else {
+            for (int px = pl; px < LN; px += 64) {
+                const int r = px / LW, c = px - r * LW;
+                const u32x4 rt = LrT[r], ct = LrT[LW + c];
+                const float wy0 = __uint_as_float(rt.z), wy1 = __uint_as_float(rt.w), wx0 = __uint_as_float(ct.z), wx1 = __uint_as_float(ct.w);
+                const f32x4 v0 = lrg[rt.x + ct.x], v1 = lrg[rt.x + ct.y], v2 = lrg[rt.y + ct.x], v3 = lrg[rt.y + ct.y];
+                BIGf[g16 * LPL + px] = wy0 * (wx0 * v0 + wx1 * v1) + wy1 * (wx0 * v2 + wx1 * v3);
+            }
         }
     }
     __syncthreads();
@@ -262,41 +370,18 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     __syncthreads();
     RR_STAMP(2);
 
-    // ------------------------------------------------------------------ phase 2: gather + bilinear warp of the region into LDS
-    // unit = (region pixel, channel group): 16 lanes read one whole 256-byte pixel per tap
     if (RR_ON(1)) {
-        RR_TID(t);
-        const float *img = p.ref[n];
-        const int g16 = t & 15, pl = t >> 4;
-        const unsigned row_off = (unsigned)Wp * CH;
-        auto issue = [&](int k, f32x4 (&v)[4], f32x4 &w) {
-            const int pix = pl + 64 * k;
-            const unsigned o = TapO[pix];
-            w = TapW[pix];
-            const float *a = img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
-            const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? row_off : 0u;
-            v[0] = *reinterpret_cast<const f32x4 *>(a);
-            v[1] = *reinterpret_cast<const f32x4 *>(a + dxo);
-            v[2] = *reinterpret_cast<const f32x4 *>(a + dyo);
-            v[3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
-        };
-        auto commit = [&](int k, const f32x4 (&v)[4], const f32x4 w) {
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            acc += v[0] * (w[0] * w[2]);      // same order as warp_mvq_nhwc_kernel
-            acc += v[1] * (w[1] * w[2]);
-            acc += v[2] * (w[0] * w[3]);
-            acc += v[3] * (w[1] * w[3]);
-            BIGf[g16 * HPL + pl + 64 * k] = acc;
-        };
-        f32x4 v[5][4], w[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) issue(k, v[k], w[k]);
+        for (int k = 0; k < G1; ++k) g_commit(k, gv[k]);
+        constexpr int GB = RR_GB;          // units per later batch
 #pragma unroll
-        for (int k = 0; k < 5; ++k) commit(k, v[k], w[k]);
+        for (int k0 = G1; k0 < GU; k0 += GB) {
+            f32x4 v[GB][4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) issue(5 + k, v[k], w[k]);
+            for (int k = 0; k < GB; ++k) if (k0 + k < GU) g_issue(k0 + k, v[k]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) commit(5 + k, v[k], w[k]);
+            for (int k = 0; k < GB; ++k) if (k0 + k < GU) g_commit(k0 + k, v[k]);
+        }
     }
     __syncthreads();
     RR_STAMP(3);
@@ -310,6 +395,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         const int xr = 8 * (r4 & 1) + xi, rb = 11 * (r4 >> 1);
 #pragma unroll
         for (int j = 0; j < 13; ++j) h[j] = BIGf[wave * HPL + (RR_ON(2) ? (rb + j) * R4W + xr : 0)];
+        if (tile + nslot < t_hi) mv_fetch(tile + nslot);       // the tap tables are dead
     }
     __syncthreads();
     RR_STAMP(4);
@@ -359,6 +445,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         }
     };
     if (RR_ON(4)) conv_records(p.wk, p.bk, KPLK);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile's motion vectors have landed long ago
     __syncthreads();
     RR_STAMP(5);
 
