@@ -50,7 +50,7 @@ constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
 #ifndef RR_G1
-#define RR_G1 4       // gather units requested ahead of the query conv
+#define RR_G1 1       // gather units requested ahead of the query conv
 #endif
 #ifndef RR_GB
 #define RR_GB 5       // gather units per later batch
@@ -279,35 +279,67 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     // Gather unit = (region pixel, channel group): 16 lanes read one whole 256-byte pixel per tap.  The staged region overwrites the
     // lr_up tile, so it can only be WRITTEN after the query conv -- but the taps of the first G1 units are REQUESTED before it and
     // travel while the conv runs (their 16 G1 registers are free here: neither the columns nor the softmax weights are live yet).
-    constexpr int G1 = RR_G1, GU = 9;
+    // Gather unit = a 2 x 2 block of region pixels x 16 channel groups (16 lanes).  When the four pixels sample one rigid 3 x 3 source
+    // neighbourhood (equal motion vectors -- codec MVs are block constant -- and no clamping at the image border) the block costs 9
+    // pixel loads instead of 16: the gather is bound by the bytes the texture path returns (64 B / clk / CU).  Other blocks take
+    // the per-pixel path at commit time.
+    constexpr int G1 = RR_G1, GU = 3, BW = R4W / 2, NBLK = BW * BW;       // 144 blocks: rounds 0, 1 full, round 2 = waves 0..3
     const float *g_img = p.ref[n];
     const unsigned g_row_off = (unsigned)Wp * CH;
-    auto g_issue = [&](int k, f32x4 (&v)[4]) {
+    auto g_issue = [&](int k, f32x4 (&v)[9]) -> bool {
         RR_TID(t);
-        const int g16 = t & 15, pix = (t >> 4) + 64 * k;
-        const unsigned o = TapO[pix];
-        const float *a = g_img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
-        const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? g_row_off : 0u;
-        v[0] = *reinterpret_cast<const f32x4 *>(a);
-        v[1] = *reinterpret_cast<const f32x4 *>(a + dxo);
-        v[2] = *reinterpret_cast<const f32x4 *>(a + dyo);
-        v[3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
+        const int g16 = t & 15, u = (t >> 4) + 64 * k;
+        if (k == GU - 1 && u >= NBLK) return false;
+        const int by = u / BW, p00 = 2 * by * R4W + 2 * (u - by * BW);
+        const unsigned o00 = TapO[p00], o01 = TapO[p00 + 1], o10 = TapO[p00 + R4W], o11 = TapO[p00 + R4W + 1];
+        const bool rigid = (o00 >> 30) == 3u && o01 == o00 + 1u && o10 == o00 + (unsigned)Wp && o11 == o10 + 1u;
+        // (unconditional: other blocks read the 3 x 3 pixels at the image origin and drop them -- a branch around the loads makes hipcc
+        // spill their destination registers)
+        const float *a = g_img + (size_t)(rigid ? o00 & 0x3FFFFFFFu : 0u) * CH + g16 * 4;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[3 * r + c] = *reinterpret_cast<const f32x4 *>(a + r * g_row_off + c * CH);
+        return rigid;
     };
-    auto g_commit = [&](int k, const f32x4 (&v)[4]) {
-        RR_TID(t);
-        const int g16 = t & 15, pix = (t >> 4) + 64 * k;
-        const f32x4 w = TapW[pix];
+    auto g_blend = [&](const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d, const f32x4 w) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        acc += v[0] * (w[0] * w[2]);      // same order as warp_mvq_nhwc_kernel
-        acc += v[1] * (w[1] * w[2]);
-        acc += v[2] * (w[0] * w[3]);
-        acc += v[3] * (w[1] * w[3]);
-        BIGf[g16 * HPL + pix] = acc;
+        acc += a * (w[0] * w[2]);      // same order as warp_mvq_nhwc_kernel
+        acc += b * (w[1] * w[2]);
+        acc += c * (w[0] * w[3]);
+        acc += d * (w[1] * w[3]);
+        return acc;
     };
-    f32x4 gv[G1 > 0 ? G1 : 1][4];
+    auto g_commit = [&](int k, const f32x4 (&v)[9], bool rigid) {
+        RR_TID(t);
+        const int g16 = t & 15, u = (t >> 4) + 64 * k;
+        if (k == GU - 1 && u >= NBLK) return;
+        const int by = u / BW, p00 = 2 * by * R4W + 2 * (u - by * BW);
+        f32x4 *dst = BIGf + g16 * HPL + p00;
+        if (rigid) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    dst[i * R4W + j] = g_blend(v[3 * i + j], v[3 * i + j + 1], v[3 * i + 3 + j], v[3 * i + 4 + j], TapW[p00 + i * R4W + j]);
+        } else {
+#pragma unroll 1
+            for (int q = 0; q < 4; ++q) {                    // rare: one pixel at a time keeps the register footprint of the common path
+                const int pq = p00 + (q >> 1) * R4W + (q & 1);
+                const unsigned o = TapO[pq];
+                const float *a = g_img + (size_t)(o & 0x3FFFFFFFu) * CH + g16 * 4;
+                const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? g_row_off : 0u;
+                const f32x4 x0 = *reinterpret_cast<const f32x4 *>(a), x1 = *reinterpret_cast<const f32x4 *>(a + dxo);
+                const f32x4 x2 = *reinterpret_cast<const f32x4 *>(a + dyo), x3 = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
+                BIGf[g16 * HPL + pq] = g_blend(x0, x1, x2, x3, TapW[pq]);
+            }
+        }
+    };
+    f32x4 gv[G1 > 0 ? G1 : 1][9];
+    bool grigid[G1 > 0 ? G1 : 1];
     if (RR_ON(1)) {
 #pragma unroll
-        for (int k = 0; k < G1; ++k) g_issue(k, gv[k]);
+        for (int k = 0; k < G1; ++k) grigid[k] = g_issue(k, gv[k]);
     }
 
     // ------------------------------------------------------------------ phase 0b: lr_up tile (+1 halo, all 64 channels) into LDS
@@ -372,15 +404,14 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 
     if (RR_ON(1)) {
 #pragma unroll
-        for (int k = 0; k < G1; ++k) g_commit(k, gv[k]);
-        constexpr int GB = RR_GB;          // units per later batch
+        for (int k = 0; k < G1; ++k) g_commit(k, gv[k], grigid[k]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k0 = G1; k0 < GU; k0 += GB) {
-            f32x4 v[GB][4];
-#pragma unroll
-            for (int k = 0; k < GB; ++k) if (k0 + k < GU) g_issue(k0 + k, v[k]);
-#pragma unroll
-            for (int k = 0; k < GB; ++k) if (k0 + k < GU) g_commit(k0 + k, v[k]);
+        for (int k = G1; k < GU; ++k) {
+            f32x4 v[9];
+            const bool rigid = g_issue(k, v);
+            g_commit(k, v, rigid);
+            __builtin_amdgcn_sched_barrier(0);       // one round at a time: two rounds in flight (72 registers) spill
         }
     }
     __syncthreads();
