@@ -50,7 +50,10 @@ constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
 #ifndef RR_G1
-#define RR_G1 1       // gather units requested ahead of the query conv
+#define RR_G1 2       // gather units requested ahead of the query conv
+#endif
+#ifndef RR_PEARLY
+#define RR_PEARLY 0   // 1: the single-pixel round is requested ahead of the query conv as well
 #endif
 #ifndef RR_GB
 #define RR_GB 5       // gather units per later batch
@@ -283,23 +286,26 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     // neighbourhood (equal motion vectors -- codec MVs are block constant -- and no clamping at the image border) the block costs 9
     // pixel loads instead of 16: the gather is bound by the bytes the texture path returns (64 B / clk / CU).  Other blocks take
     // the per-pixel path at commit time.
-    constexpr int G1 = RR_G1, GU = 3, BW = R4W / 2, NBLK = BW * BW;       // 144 blocks: rounds 0, 1 full, round 2 = waves 0..3
+    constexpr int G1 = RR_G1, GU = 2, BW = R4W / 2;       // 144 blocks: two rounds of 64; the pixels of the last 16 blocks one by one (64 units)
     const float *g_img = p.ref[n];
     const unsigned g_row_off = (unsigned)Wp * CH;
-    auto g_issue = [&](int k, f32x4 (&v)[9]) -> bool {
+    auto g_prep = [&](int k, const float *&a) -> bool {
         RR_TID(t);
         const int g16 = t & 15, u = (t >> 4) + 64 * k;
-        if (k == GU - 1 && u >= NBLK) return false;
         const int by = u / BW, p00 = 2 * by * R4W + 2 * (u - by * BW);
         const unsigned o00 = TapO[p00], o01 = TapO[p00 + 1], o10 = TapO[p00 + R4W], o11 = TapO[p00 + R4W + 1];
         const bool rigid = (o00 >> 30) == 3u && o01 == o00 + 1u && o10 == o00 + (unsigned)Wp && o11 == o10 + 1u;
-        // (unconditional: other blocks read the 3 x 3 pixels at the image origin and drop them -- a branch around the loads makes hipcc
-        // spill their destination registers)
-        const float *a = g_img + (size_t)(rigid ? o00 & 0x3FFFFFFFu : 0u) * CH + g16 * 4;
+        // (the loads are unconditional: other blocks read the 3 x 3 pixels at the image origin and drop them -- a branch around the
+        // loads makes hipcc spill their destination registers)
+        a = g_img + (size_t)(rigid ? o00 & 0x3FFFFFFFu : 0u) * CH + g16 * 4;
+        return rigid;
+    };
+    auto g_load = [&](const float *a, int j) { return *reinterpret_cast<const f32x4 *>(a + (j / 3) * g_row_off + (j % 3) * CH); };
+    auto g_issue = [&](int k, f32x4 (&v)[9]) -> bool {
+        const float *a;
+        const bool rigid = g_prep(k, a);
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) v[3 * r + c] = *reinterpret_cast<const f32x4 *>(a + r * g_row_off + c * CH);
+        for (int j = 0; j < 9; ++j) v[j] = g_load(a, j);
         return rigid;
     };
     auto g_blend = [&](const f32x4 a, const f32x4 b, const f32x4 c, const f32x4 d, const f32x4 w) {
@@ -313,7 +319,6 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     auto g_commit = [&](int k, const f32x4 (&v)[9], bool rigid) {
         RR_TID(t);
         const int g16 = t & 15, u = (t >> 4) + 64 * k;
-        if (k == GU - 1 && u >= NBLK) return;
         const int by = u / BW, p00 = 2 * by * R4W + 2 * (u - by * BW);
         f32x4 *dst = BIGf + g16 * HPL + p00;
         if (rigid) {
@@ -335,34 +340,57 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             }
         }
     };
+    // the 64 pixels of blocks 128..143, one per 16-lane group (general path: clamped taps, always valid -- every lane has work in every
+    // round, and nothing is defined under a branch: hipcc spills registers that are)
+    auto p_pix = [&]() { RR_TID(t); const int u = 2 * 64 + (t >> 6), q = (t >> 4) & 3, by = u / BW; return 2 * by * R4W + 2 * (u - by * BW) + (q >> 1) * R4W + (q & 1); };
+    auto p_issue = [&](f32x4 (&x)[4]) {
+        RR_TID(t);
+        const unsigned o = TapO[p_pix()];
+        const float *a = g_img + (size_t)(o & 0x3FFFFFFFu) * CH + (t & 15) * 4;
+        const unsigned dxo = (o & 0x40000000u) ? CH : 0u, dyo = (o & 0x80000000u) ? g_row_off : 0u;
+        x[0] = *reinterpret_cast<const f32x4 *>(a); x[1] = *reinterpret_cast<const f32x4 *>(a + dxo);
+        x[2] = *reinterpret_cast<const f32x4 *>(a + dyo); x[3] = *reinterpret_cast<const f32x4 *>(a + dyo + dxo);
+    };
+    auto p_commit = [&](const f32x4 (&x)[4]) {
+        RR_TID(t);
+        const int pq = p_pix();
+        BIGf[(t & 15) * HPL + pq] = g_blend(x[0], x[1], x[2], x[3], TapW[pq]);
+    };
+    // The requests of the first G1 rounds are spread over the lr_up units below: issued in one burst they fill the texture path's
+    // queue and the waves sit in the issue stage until it drains, with nothing overlapped.
     f32x4 gv[G1 > 0 ? G1 : 1][9];
     bool grigid[G1 > 0 ? G1 : 1];
-    if (RR_ON(1)) {
+    const float *ga[G1 > 0 ? G1 : 1];
 #pragma unroll
-        for (int k = 0; k < G1; ++k) grigid[k] = g_issue(k, gv[k]);
-    }
+    for (int k = 0; k < G1; ++k) grigid[k] = g_prep(k, ga[k]);
 
     // ------------------------------------------------------------------ phase 0b: lr_up tile (+1 halo, all 64 channels) into LDS
-    if (RR_ON(2)) {
+    {
         RR_TID(t);
         const int g16 = t & 15, pl = t >> 4;
         const f32x4 *lrg = reinterpret_cast<const f32x4 *>(p.lr + (size_t)n * p.hp * p.wp * CH) + g16;
         const f32x4 *wb = LwA + g16;
-        // (two separate loops: with the LDS and the global taps merged into one, hipcc waits for vmcnt(0) -- i.e. for the gather
-        // requests in flight -- before every interpolation)
-        if (win_lds) {
+        constexpr int NL = G1 > 0 ? 9 : 0;       // round 0 here (a wave can post ~9 requests before the texture queue stalls it); round 1 ahead of the query conv
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int px = pl + 64 * k;
-                if (k < 5 || px < LN) {
-                    const int r = px / LW, c = px - r * LW;
-                    const u32x4 rt = LrT[r], ct = LrT[LW + c];
-                    const float wy0 = __uint_as_float(rt.z), wy1 = __uint_as_float(rt.w), wx0 = __uint_as_float(ct.z), wx1 = __uint_as_float(ct.w);
-                    const f32x4 v0 = wb[rt.x + ct.x], v1 = wb[rt.x + ct.y], v2 = wb[rt.y + ct.x], v3 = wb[rt.y + ct.y];
-                    BIGf[g16 * LPL + px] = wy0 * (wx0 * v0 + wx1 * v1) + wy1 * (wx0 * v2 + wx1 * v3);
-                }
+        for (int k = 0; k < 6; ++k) {
+            if (RR_ON(1)) {
+#pragma unroll
+                for (int j = k * NL / 6; j < (k + 1) * NL / 6; ++j) gv[0][j] = g_load(ga[0], j);
             }
-        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            const int px = pl + 64 * k;
+            if (win_lds && RR_ON(2) && (k < 5 || px < LN)) {
+                const int r = px / LW, c = px - r * LW;
+                const u32x4 rt = LrT[r], ct = LrT[LW + c];
+                const float wy0 = __uint_as_float(rt.z), wy1 = __uint_as_float(rt.w), wx0 = __uint_as_float(ct.z), wx1 = __uint_as_float(ct.w);
+                const f32x4 v0 = wb[rt.x + ct.x], v1 = wb[rt.x + ct.y], v2 = wb[rt.y + ct.x], v3 = wb[rt.y + ct.y];
+                BIGf[g16 * LPL + px] = wy0 * (wx0 * v0 + wx1 * v1) + wy1 * (wx0 * v2 + wx1 * v3);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // without the staged window (other scales): taps from global memory.  A separate loop: with the LDS and the global taps merged
+        // into one, hipcc waits for vmcnt(0) -- i.e. for the gather requests in flight -- before every interpolation.
+        if (!win_lds && RR_ON(2)) {
             for (int px = pl; px < LN; px += 64) {
                 const int r = px / LW, c = px - r * LW;
                 const u32x4 rt = LrT[r], ct = LrT[LW + c];
@@ -376,6 +404,16 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     RR_STAMP(1);
 
     // ------------------------------------------------------------------ phase 1: query conv, lane local (channels 16c + 4g .. +3 of the lane's own query)
+    if (RR_ON(1)) {
+#pragma unroll
+        for (int k = 1; k < G1; ++k)
+#pragma unroll
+            for (int j = 0; j < 9; ++j) gv[k][j] = g_load(ga[k], j);
+    }
+#if RR_PEARLY
+    f32x4 gx[4];
+    if (RR_ON(1)) p_issue(gx);
+#endif
     u32x2 qh[4], ql[4];
     {
         RR_TID(t);
@@ -406,12 +444,21 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 #pragma unroll
         for (int k = 0; k < G1; ++k) g_commit(k, gv[k], grigid[k]);
         __builtin_amdgcn_sched_barrier(0);
+        {       // the remaining rounds in flight together
+            f32x4 v[GU - G1 > 0 ? GU - G1 : 1][9], x[4];
+            bool rg[GU - G1 > 0 ? GU - G1 : 1];
 #pragma unroll
-        for (int k = G1; k < GU; ++k) {
-            f32x4 v[9];
-            const bool rigid = g_issue(k, v);
-            g_commit(k, v, rigid);
-            __builtin_amdgcn_sched_barrier(0);       // one round at a time: two rounds in flight (72 registers) spill
+            for (int k = G1; k < GU; ++k) rg[k - G1] = g_issue(k, v[k - G1]);
+#if RR_PEARLY
+            p_commit(gx);
+#else
+            p_issue(x);
+#endif
+#pragma unroll
+            for (int k = G1; k < GU; ++k) g_commit(k, v[k - G1], rg[k - G1]);
+#if !RR_PEARLY
+            p_commit(x);
+#endif
         }
     }
     __syncthreads();
