@@ -127,6 +127,14 @@ __device__ __forceinline__ float rows_sum(float x) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// a wave-uniform double pinned to scalar registers (uniform fp64 values are computed on the VALU; left in VGPRs across the tile loop
+// they are spilled to scratch and reloaded -- a memory round trip -- in the phase that uses them)
+__device__ __forceinline__ double uniform_f64(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    unsigned lo, hi;                                 // (asm: the builtin is sunk to the use and the VGPR pair stays live)
+    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"((unsigned)u), "v"((unsigned)(u >> 32)));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ int key_rec(int b, int k0, int base0) { return base0 + 24 * b + (k0 >= 14 - 2 * b ? 8 : 0); }
 
 #ifdef RR_TIMING
@@ -182,19 +190,21 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     // lane's own slot of the tap-offset table (dead between the gather and the next tile's tap arithmetic): a register would be
     // live across the whole tile and hipcc spills it (scratch traffic + a vmcnt(0) at the request).
     const bool mv_ident = p.Hp == p.H && p.Wp == p.W;
+    const double g_dW = uniform_f64((double)max(p.Wp - 1, 1)), g_dH = uniform_f64((double)max(p.Hp - 1, 1)), g_rW = uniform_f64(1.0 / g_dW), g_rH = uniform_f64(1.0 / g_dH);      // grid normalisation: extents and their reciprocals
+#define RR_TID(t) int t = tid0; asm volatile("" : "+v"(t))
     auto mv_fetch = [&](int tile_) {
         const int n_ = tile_ / per_img, tr_ = tile_ - n_ * per_img;
-        const int yr = tid0 / R4W, xr = tid0 - yr * R4W;
+        RR_TID(tq);
+        const int yr = tq / R4W, xr = tq - yr * R4W;
         const int gy = (tr_ / p.tiles_x) * TY - 4 + yr, gx = (tr_ - (tr_ / p.tiles_x) * p.tiles_x) * TX - 4 + xr;
-        if (mv_ident && tid0 < R4N && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)
-            dma4_glb(p.mv + ((size_t)n_ * p.H * p.W + (size_t)gy * p.W + gx) * 2, lds_addr(TapO) + (unsigned)__builtin_amdgcn_readfirstlane(tid0 >> 6) * 256u);
+        if (mv_ident && tq < R4N && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp)
+            dma4_glb(p.mv + ((size_t)n_ * p.H * p.W + (size_t)gy * p.W + gx) * 2, lds_addr(TapO) + (unsigned)__builtin_amdgcn_readfirstlane(tq >> 6) * 256u);
     };
     if (t_lo + slot < t_hi) mv_fetch(t_lo + slot);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int tile = t_lo + slot; tile < t_hi; tile += nslot) {
     // Everything derived from the thread id is recomputed per phase from an opaque copy: left alone, LLVM hoists the per-lane
     // constants of all phases (record indices, masks, addresses) to the top of the tile loop where they occupy ~100 registers.
-#define RR_TID(t) int t = tid0; asm volatile("" : "+v"(t))
 #ifdef RR_TIMING
     unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
 #endif
@@ -249,11 +259,15 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                 if (mv_ident) {                        // identity resize (PSPNet): (q/4 * Hp) / H == q/4 exactly
                     fx = (double)(short)(mv_cur & 0xFFFFu) / 4.0; fy = (double)(short)(mv_cur >> 16) / 4.0;
                 } else {
-                    mv_at(p.mv + (size_t)n * p.H * p.W * 2, p.H, p.W, Hp, Wp, gy, gx, fx, fy);
+                    int H_ = p.H, W_ = p.W, Hp_ = Hp, Wp_ = Wp;   // opaque: keeps the fp64 scale factors of this (rare) path from being hoisted
+                    asm volatile("" : "+s"(H_), "+s"(W_), "+s"(Hp_), "+s"(Wp_));      // out of the tile loop, where they would sit in spilled registers
+                    mv_at(p.mv + (size_t)n * p.H * p.W * 2, H_, W_, Hp_, Wp_, gy, gx, fx, fy);
                 }
                 float ngx, ngy;
-                norm_grid<double>(gx, gy, fx, fy, Hp, Wp, ngx, ngy);
-                const Taps tp = make_taps(ngx, ngy, Hp, Wp);
+                norm_grid_rcp(gx, gy, fx, fy, g_dW, g_dH, g_rW, g_rH, ngx, ngy);
+                int Hq = Hp, Wq = Wp;                  // opaque: (float)W etc. are converted here, not hoisted into (spilled) loop-invariant VGPRs
+                asm volatile("" : "+s"(Hq), "+s"(Wq));
+                const Taps tp = make_taps(ngx, ngy, Hq, Wq);
                 const int xa = min(max(tp.x0, 0), Wp - 1), xc = min(max(tp.x0 + 1, 0), Wp - 1);
                 const int ya = min(max(tp.y0, 0), Hp - 1), yc = min(max(tp.y0 + 1, 0), Hp - 1);
                 o = (unsigned)(ya * Wp + xa) | ((unsigned)(xc - xa) << 30) | ((unsigned)(yc - ya) << 31);
@@ -701,6 +715,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                 }
         }
     }
+    RR_STAMP(13);
     __syncthreads();          // the next tile's tables / staging overwrite LDS this tile still reads
     RR_STAMP(8);
 #ifdef RR_TIMING

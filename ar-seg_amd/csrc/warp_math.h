@@ -35,6 +35,19 @@ __device__ __forceinline__ void norm_grid(int x, int y, FT fx, FT fy, int H, int
     gy = (float)((FT)2.0 * vy / (FT)max(H - 1, 1) - (FT)1.0);
 }
 
+// The same with the two divisions by the (uniform) extents replaced by a*y + one correction step, y = RN(1/b) computed once per
+// kernel with a true division: q0 = RN(a*y), r = a - b*q0 (exact in an fma), q = RN(q0 + r*y) is the correctly rounded quotient a/b
+// (Markstein) -- the values match norm_grid<double>, the 2 x 12 slow fp64 instructions of the division expansion become 2 x 3.
+__device__ __forceinline__ double div_by_rcp(double a, double b, double y) {
+    const double q0 = a * y;
+    return __builtin_fma(__builtin_fma(-q0, b, a), y, q0);
+}
+__device__ __forceinline__ void norm_grid_rcp(int x, int y, double fx, double fy, double dW, double dH, double rW, double rH, float &gx, float &gy) {
+    const double vx = (double)(float)x + fx, vy = (double)(float)y + fy;
+    gx = (float)(div_by_rcp(2.0 * vx, dW, rW) - 1.0);
+    gy = (float)(div_by_rcp(2.0 * vy, dH, rH) - 1.0);
+}
+
 // (mv_q/4) * Hp/H resampled to (Hp,Wp) with align_corners=True, in fp64 like the reference
 __device__ __forceinline__ void mv_at(const int16_t *__restrict__ mv, int H, int W, int Hp, int Wp, int y, int x,
                                       double &fx, double &fy) {
