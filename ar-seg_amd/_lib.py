@@ -30,7 +30,7 @@ class ConvDesc(Structure):
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int),
                 ("batch", c_int), ("in_batch_stride", c_int64), ("w_batch_stride", c_int64), ("out_batch_stride", c_int64),
-                ("math", c_int)]
+                ("math", c_int), ("upsample2x", c_int)]
 
 
 _P = c_void_p  # device or host pointer passed as integer

@@ -56,6 +56,7 @@ struct ConvParams {
     int ktiles, ktiles_per_split, nsplit, N_batch;
     int tiles_m, tiles_n;
     int inv_S;                       // 65536/S + 1: r = (rs*inv_S) >> 16 without a division
+    int up2;                         // patch kernel: `in` is the low-resolution tensor [N, H/2, W/2, in_ld], convolved after a x2 bilinear upsample
     unsigned in_bytes, w_bytes;      // extents for the buffer descriptors
     long long in_bs, w_bs, out_bs;   // batched GEMM mode (blockIdx.y = batch index): element strides between problems
 };
@@ -356,13 +357,20 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
 // the nine taps are A-fragment *address offsets* into that patch.  K order = (chunk, tap), i.e. K tile kt = tap*Cin/32 +
 // chunk of the ordinary packed weights.  Per tap only the weight tile is streamed (double buffered, one barrier per tap);
 // the next chunk's patch is prefetched into registers under the nine taps of the current one.
-template <int BN, int WM>      // WM wave rows of 64 output pixels each: BM = 64*WM pixels, 2*WM waves
+//
+// UP2: the conv input is the x2 bilinear (align_corners=False) upsample of `p.in` (PSPUpsample, model/pspnet.py:43-46), never
+// materialised.  The patch starts at the odd coordinate ty0 - 1: it is a grid of 2 x 2 blocks (rows 2i+1, 2i+2) and each block is a
+// blend of exactly ONE 2 x 2 quad of low-resolution pixels (rows i, i+1: weights .75/.25 and .25/.75) -- one 16-byte load per
+// upsampled 16-byte piece, a quarter of the bytes of the materialised tensor, and no resize kernel (its 0.25/0.75 arithmetic and
+// edge cases, layers.hip upsample2x_nhwc_kernel, are reproduced).  Dilation 1.
+template <int BN, int WM, bool UP2>      // WM wave rows of 64 output pixels each: BM = 64*WM pixels, 2*WM waves
 __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_kernel(const ConvParams p, int TW, int log2TW) {
     constexpr int ROWB = 144;                          // bytes per LDS row: 32 hi + 32 lo halves + pad (conflict-free b128 reads)
     constexpr int NT = 128 * WM, BM = 64 * WM;
     constexpr int TN = BN / 64, TM = 2, RB = (BN * 8 + NT - 1) / NT, RPB = NT / 8;
     constexpr unsigned OOB = 0x80000000u;
-    constexpr int MAXI = WM == 2 ? 9 : 7;              // patch items (pixel, 16-byte piece) per thread: <= 288 / 448 pixels
+    constexpr int MAXI = UP2 ? 1 : (WM == 2 ? 9 : 7);  // patch items (pixel, 16-byte piece) per thread: <= 288 / 448 pixels
+    constexpr int MAXU = UP2 ? (WM == 2 ? 3 : 2) : 1;  // UP2: items (2 x 2 block, 16-byte piece) per thread: <= 72 / 112 blocks
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int TH = BM >> log2TW, d = p.dil, PW = TW + 2 * d, PH = TH + 2 * d, npx = PW * PH;
     unsigned char *Ps = reinterpret_cast<unsigned char *>(smem);               // [npx][ROWB]
@@ -386,12 +394,37 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
 
     // patch items of this thread: item i = (pixel i/8, piece i%8); global byte offset without the chunk term, or OOB
     unsigned poff[MAXI];
+    if constexpr (!UP2) {
 #pragma unroll
-    for (int it = 0; it < MAXI; ++it) {
-        const int i = tid + it * NT, px = i >> 3, py = px / PW, pxx = px - py * PW;
-        const int gy = ty0 - d + py, gx = tx0 - d + pxx;
-        const bool ok = px < npx && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        poff[it] = ok ? (unsigned)((((img * p.H + gy) * p.W + gx) * p.in_ld) * 4 + (i & 7) * 16) : OOB;
+        for (int it = 0; it < MAXI; ++it) {
+            const int i = tid + it * NT, px = i >> 3, py = px / PW, pxx = px - py * PW;
+            const int gy = ty0 - d + py, gx = tx0 - d + pxx;
+            const bool ok = px < npx && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            poff[it] = ok ? (unsigned)((((img * p.H + gy) * p.W + gx) * p.in_ld) * 4 + (i & 7) * 16) : OOB;
+        }
+    }
+    // UP2 items: block (by, bx) of the patch = upsampled rows 2*iy+1, 2*iy+2 and columns 2*ix+1, 2*ix+2; quad = low-res rows
+    // clamp(iy), clamp(iy+1) x columns clamp(ix), clamp(ix+1).  uflag: bit 0/1 row 0/1 inside the image, bit 2/3 column 0/1 inside,
+    // bit 4: iy < 0 (row 1 is the image's first row = the low-res row itself), bit 5: ix < 0.
+    unsigned uoff[MAXU][4];
+    int upx[MAXU], uflag[MAXU];
+    if constexpr (UP2) {
+        const int h = p.H >> 1, w = p.W >> 1, BWc = PW >> 1, nblkp = BWc * (PH >> 1);
+#pragma unroll
+        for (int it = 0; it < MAXU; ++it) {
+            const int i = tid + it * NT, b = i >> 3, by = b / BWc, bx = b - by * BWc;
+            const int iy = (ty0 >> 1) - 1 + by, ix = (tx0 >> 1) - 1 + bx;
+            const int ya = min(max(iy, 0), h - 1), yb = min(max(iy + 1, 0), h - 1), xa = min(max(ix, 0), w - 1), xb = min(max(ix + 1, 0), w - 1);
+            const unsigned base = (unsigned)(img * h) * (unsigned)w, q16 = (i & 7) * 16;
+            const bool live = b < nblkp;
+            uoff[it][0] = live ? ((base + ya * w + xa) * p.in_ld) * 4u + q16 : OOB;
+            uoff[it][1] = live ? ((base + ya * w + xb) * p.in_ld) * 4u + q16 : OOB;
+            uoff[it][2] = live ? ((base + yb * w + xa) * p.in_ld) * 4u + q16 : OOB;
+            uoff[it][3] = live ? ((base + yb * w + xb) * p.in_ld) * 4u + q16 : OOB;
+            upx[it] = live ? (2 * by * PW + 2 * bx) : -1;
+            uflag[it] = ((iy >= 0 && 2 * iy + 1 < p.H) ? 1 : 0) | ((2 * iy + 2 < p.H) ? 2 : 0) | ((ix >= 0 && 2 * ix + 1 < p.W) ? 4 : 0) |
+                        ((2 * ix + 2 < p.W) ? 8 : 0) | (iy < 0 ? 16 : 0) | (ix < 0 ? 32 : 0);
+        }
     }
     const int chunk = tid & 7, row0 = tid >> 3;
     unsigned woff[RB];
@@ -404,20 +437,49 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
 
     struct BRegs { u32x4 v[RB]; };
     u32x4 rp[MAXI];
+    u32x4 rq[MAXU][4];
     auto load_patch = [&](int ck) {
+        if constexpr (UP2) {
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it) rp[it] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, poff[it] + (unsigned)(ck * 128), 0, 0);
+            for (int it = 0; it < MAXU; ++it)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) rq[it][k] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, uoff[it][k] + (unsigned)(ck * 128), 0, 0);
+        } else {
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) rp[it] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, poff[it] + (unsigned)(ck * 128), 0, 0);
+        }
+    };
+    auto put_px = [&](int px, int piece, const f32x4 v) {
+        uint2 hi, lo;
+        split_f16x3(v, hi, lo);
+        unsigned char *row = Ps + px * ROWB + piece * 8;
+        *reinterpret_cast<uint2 *>(row) = hi;
+        *reinterpret_cast<uint2 *>(row + 64) = lo;
     };
     auto store_patch = [&]() {
+        if constexpr (UP2) {
 #pragma unroll
-        for (int it = 0; it < MAXI; ++it) {
-            const int i = tid + it * NT, px = i >> 3;
-            if (px < npx) {
-                uint2 hi, lo;
-                split_f16x3(__builtin_bit_cast(f32x4, rp[it]), hi, lo);
-                unsigned char *row = Ps + px * ROWB + (i & 7) * 8;
-                *reinterpret_cast<uint2 *>(row) = hi;
-                *reinterpret_cast<uint2 *>(row + 64) = lo;
+            for (int it = 0; it < MAXU; ++it) {
+                if (upx[it] < 0) continue;
+                const int piece = (tid + it * NT) & 7, f = uflag[it];
+                const f32x4 q00 = __builtin_bit_cast(f32x4, rq[it][0]), q01 = __builtin_bit_cast(f32x4, rq[it][1]);
+                const f32x4 q10 = __builtin_bit_cast(f32x4, rq[it][2]), q11 = __builtin_bit_cast(f32x4, rq[it][3]);
+                // vertical blend at the two low-res columns (row 2iy+1: .75 / .25; row 2iy+2: .25 / .75, or the row itself at the top edge)
+                const f32x4 r0a = 0.75f * q00 + 0.25f * q10, r0b = 0.75f * q01 + 0.25f * q11;
+                const f32x4 r1a = (f & 16) ? q10 : 0.25f * q00 + 0.75f * q10, r1b = (f & 16) ? q11 : 0.25f * q01 + 0.75f * q11;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 o00 = 0.75f * r0a + 0.25f * r0b, o01 = (f & 32) ? r0b : 0.25f * r0a + 0.75f * r0b;
+                const f32x4 o10 = 0.75f * r1a + 0.25f * r1b, o11 = (f & 32) ? r1b : 0.25f * r1a + 0.75f * r1b;
+                put_px(upx[it], piece, (f & 5) == 5 ? o00 : z);
+                put_px(upx[it] + 1, piece, (f & 9) == 9 ? o01 : z);
+                put_px(upx[it] + PW, piece, (f & 6) == 6 ? o10 : z);
+                put_px(upx[it] + PW + 1, piece, (f & 10) == 10 ? o11 : z);
+            }
+        } else {
+#pragma unroll
+            for (int it = 0; it < MAXI; ++it) {
+                const int i = tid + it * NT, px = i >> 3;
+                if (px < npx) put_px(px, i & 7, __builtin_bit_cast(f32x4, rp[it]));
             }
         }
     };
@@ -575,6 +637,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
         if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || d->math != ARSEG_MATH_F16X3 || (d->Cin & 31) || d->batch > 1 ||
             d->split_k > 1)
             return ARSEG_EUNSUPPORTED;
+        if (d->upsample2x && (d->dil != 1 || (d->H & 1) || (d->W & 1))) return ARSEG_EUNSUPPORTED;
         const int bm = d->tile_cfg >= 15 ? 256 : 128;
         const int tw = pl->Wo >= 48 ? 64 : (pl->Wo >= 24 ? 32 : 16), th = bm / tw;
         if ((th + 2 * d->dil) * (tw + 2 * d->dil) > (bm == 128 ? 288 : 448)) return ARSEG_EUNSUPPORTED;
@@ -587,6 +650,7 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
         pl->tiles_n = arseg_cdiv(d->Cout, pl->bn);
         return ARSEG_OK;
     }
+    if (d->upsample2x) return ARSEG_EUNSUPPORTED;          // only the patch-resident plans (tile_cfg 13..16) apply the upsample
     pl->bk = (d->tile_cfg >= 9 && d->tile_cfg <= 12) ? 64 : 32;
     pl->ktiles = (pl->Kpad + pl->bk - 1) / pl->bk;
     // operands are addressed through 32-bit buffer offsets
@@ -657,16 +721,20 @@ int launch_tile(const ConvParams &p, const Plan &pl, hipStream_t hs) {
     return launch<64, 64, BK, NBUF, MATH>(p, pl, hs);
 }
 
-template <int BN, int WM>
-int launch_patch(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
+template <int BN, int WM, bool UP2>
+int launch_patch_up(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
     const int tw = pl.patch_tw, th = 64 * WM / tw, npx = (th + 2 * dil) * (tw + 2 * dil);
     const size_t smem = (size_t)((npx * 144 + 255) & ~255) + (size_t)2 * BN * 144;
     static ArsegSmemAttr attr;
-    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv3x3_patch_kernel<BN, WM>), smem)) return e;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv3x3_patch_kernel<BN, WM, UP2>), smem)) return e;
     int l2 = 0;
     while ((1 << l2) < tw) ++l2;
-    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM>), dim3(pl.tiles_m * pl.tiles_n), dim3(128 * WM), smem, st, p, tw, l2);
+    hipLaunchKernelGGL((conv3x3_patch_kernel<BN, WM, UP2>), dim3(pl.tiles_m * pl.tiles_n), dim3(128 * WM), smem, st, p, tw, l2);
     return arseg_launch_status();
+}
+template <int BN, int WM>
+int launch_patch(const ConvParams &p, const Plan &pl, int dil, hipStream_t st) {
+    return p.up2 ? launch_patch_up<BN, WM, true>(p, pl, dil, st) : launch_patch_up<BN, WM, false>(p, pl, dil, st);
 }
 
 template <int MATH>
@@ -735,8 +803,10 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.out_bs = d->batch > 1 ? d->out_batch_stride : 0;
     if (d->batch > 1 && (residual || d->batch > 65535 || (d->in_batch_stride & 3) || (d->w_batch_stride & 3))) return ARSEG_EINVAL;
     hipStream_t hs = arseg_stream(stream);
+    p.up2 = d->upsample2x ? 1 : 0;
     if (pl.patch_tw) {
-        p.in_bytes = (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);
+        p.in_bytes = d->upsample2x ? (unsigned)((((long long)d->N * (d->H >> 1) * (d->W >> 1) - 1) * d->in_ld + d->Cin) * 4)
+                                   : (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);
         if (pl.bm == 256) return pl.bn == 64 ? launch_patch<64, 4>(p, pl, d->dil, hs) : launch_patch<128, 4>(p, pl, d->dil, hs);
         return pl.bn == 64 ? launch_patch<64, 2>(p, pl, d->dil, hs) : launch_patch<128, 2>(p, pl, d->dil, hs);
     }

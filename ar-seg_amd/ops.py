@@ -451,6 +451,7 @@ class _PlanCache(dict):
 
 
 _conv_plans = _PlanCache()
+_PATCH_CFGS = (13, 14, 15, 16)      # arseg_conv_desc.tile_cfg of the patch-resident 3x3 kernel (the only direct plans with a fused x2 upsample)
 
 
 def _conv_candidates(ktiles: int, cout: int, m: int, patch_ok: bool = False):
@@ -478,7 +479,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view.
     tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use).
     up2: the conv input is the x2 bilinear (align_corners=False) upsample of ``x`` (PSPUpsample, model/pspnet.py:43-46);
-    the Winograd plan applies it inside its input transform, the direct plan materialises it first."""
+    the Winograd route applies it inside its input transform, the patch-resident direct plans while they stage their input patch;
+    the GEMM-tile plans materialise it first."""
     if is16(x):
         return _conv2d16(x, pc, residual, out, up2, tile_cfg)
     _need_gpu(x, residual, out)
@@ -486,15 +488,19 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     if up2:
         x_low = x
         n_, h_, w_, c_ = x.shape
-        if tile_cfg or split_k or not (_AUTOTUNE and _WINOGRAD and getattr(pc, "wino_u", None) is not None):
-            x, x_low = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False), None          # explicit / direct-only: materialise
+        if (tile_cfg and tile_cfg not in _PATCH_CFGS) or (not tile_cfg and (split_k or not _AUTOTUNE)):
+            x, x_low = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False), None          # explicit GEMM tile / heuristic plan: materialise
         else:
-            x = x.new_empty((n_, 2 * h_, 2 * w_, c_))          # shape carrier; filled only if the direct plan is chosen
+            # shape carrier; filled only if a plan without a fused upsample is chosen (the patch-resident plans and the Winograd
+            # route interpolate while they stage their input)
+            x = torch.empty((n_, 2 * h_, 2 * w_, c_), dtype=x.dtype, device="meta")
+    dev = x_low.device if x_low is not None else x.device
     N, H, W, Cin = x.shape
     if Cin != pc.cin_pad:
         raise _lib.ArsegError(f"conv expects {pc.cin_pad} input channels (padded), got {Cin}")
     d = ConvDesc()
-    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, _nhwc_ld(x)
+    in_ld_hi = Cin if x_low is not None else _nhwc_ld(x)
+    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, in_ld_hi
     d.Cout = pc.cout
     d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
     d.act, d.prelu_slope = pc.act, pc.slope
@@ -507,7 +513,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     check(lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv_out_hw")
     Ho, Wo = ho.value, wo.value
     if out is None:
-        out = torch.empty((N, Ho, Wo, pc.cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, Ho, Wo, pc.cout), dtype=torch.float32, device=dev)
     elif tuple(out.shape) != (N, Ho, Wo, pc.cout):
         raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(N, Ho, Wo, pc.cout)}")
     d.out_ld = _nhwc_ld(out)
@@ -517,13 +523,22 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         d.res_ld = _nhwc_ld(residual)
     flops = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
 
+    up_buf = []
+
     def launch(cfg, sk, record=True):
-        if x_low is not None:                                   # direct plan on an upsampled input: materialise it
-            resize_nhwc(x_low, H, W, _lib.BILINEAR, False, out=x)
+        xin = x
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        if x_low is not None:
+            if cfg in _PATCH_CFGS:                              # the patch-resident kernel upsamples while it stages its patch
+                xin, d.upsample2x, d.in_ld = x_low, 1, _nhwc_ld(x_low)
+            else:                                               # GEMM kernel on an upsampled input: materialise it
+                if not up_buf:
+                    up_buf.append(torch.empty((N, H, W, Cin), dtype=torch.float32, device=x_low.device))
+                xin = resize_nhwc(x_low, H, W, _lib.BILINEAR, False, out=up_buf[0])
         d.tile_cfg, d.split_k = cfg, sk
         nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
-        ws = workspace(nbytes, x.device) if nbytes else None
-        args = (ctypes.byref(d), _ptr(x), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+        ws = workspace(nbytes, out.device) if nbytes else None
+        args = (ctypes.byref(d), _ptr(xin), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
         if record:
             _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=flops)
         else:
@@ -533,7 +548,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
 
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
-        key = (x.device.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
+        key = (dev.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
         wino_ok = getattr(pc, "wino_u", None) is not None and _WINOGRAD
         plan = _conv_plans.get(key)
         if plan == "wino" and not wino_ok:                      # a persisted Winograd plan with ARSEG_CONV_WINOGRAD=0: re-tune

@@ -165,6 +165,11 @@ typedef struct arseg_conv_desc {
     int batch;
     long long in_batch_stride, w_batch_stride, out_batch_stride;
     int math;          /* enum arseg_math: which MFMA back end evaluates the fp32 GEMM (selects the w_packed format too) */
+    int upsample2x;    /* 1: `in` is the LOW-resolution tensor [N, H/2, W/2, in_ld] and the conv runs on its x2 bilinear
+                          (align_corners=False) upsample, which is never materialised (PSPUpsample, model/pspnet.py:43-46): H, W stay
+                          the conv's input size, both even, dil == 1.  Patch-resident plans only (tile_cfg 13..16; the 16-bit conv
+                          ignores it); ARSEG_EUNSUPPORTED otherwise -- the Winograd route has its own fused form
+                          (arseg_wino43_input_fwd upsample2x). */
 } arseg_conv_desc;
 
 /* ARSEG_MATH_F32:   v_mfma_f32_32x32x2_f32 on the fp32 operands; w_packed from arseg_pack_conv_weight_host.

@@ -482,7 +482,7 @@ def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res, conv_math):
     assert maxdiff(direct, out) <= 2e-4
 
 
-@pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32)])
+@pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32), (3, 33, 70, 64, 128), (2, 7, 40, 64, 64)])
 def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     """PSPUpsample: F.upsample(x2, bilinear, align_corners=False) -> conv3x3 (+BN+PReLU), upsample fused into the Winograd
     input transform (borders included) vs materialised + direct."""
@@ -506,6 +506,14 @@ def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     assert maxdiff(got.permute(0, 3, 1, 2), want) <= 2e-4
     got2 = ops.conv2d(xd, pc, up2=True, tile_cfg=7, split_k=1)   # forced direct
     assert maxdiff(got2.permute(0, 3, 1, 2), want) <= 2e-4
+    if conv_math == "f16x3":
+        # patch-resident plans: the upsample is applied while the input patch is staged (one low-resolution quad per 2 x 2 block of
+        # the patch); must equal the materialised upsample + the same kernel, edges and odd sizes included
+        for cfg in (13, 15) + ((14, 16) if Cout > 64 else ()):
+            got3 = ops.conv2d(xd, pc, up2=True, tile_cfg=cfg, split_k=1)
+            assert maxdiff(got3.permute(0, 3, 1, 2), want) <= 2e-4, cfg
+            mat = ops.conv2d(ops.resize_nhwc(xd, 2 * h, 2 * w, _lib.BILINEAR, False), pc, tile_cfg=cfg, split_k=1)
+            assert maxdiff(got3, mat) <= 1e-5, cfg
 
 
 def test_conv2d_f16x3_accuracy(dev):
