@@ -1,19 +1,20 @@
 #!/bin/bash
 # Collects the round's evidence on the MI355X box (run from the repo root through gpurun):
-#   bash profiles/collect.sh <tag>            -> gpurun_out/<tag>_*   (copy the summaries you keep into profiles/)
+#   bash profiles/collect.sh <tag> [config]   -> gpurun_out/<tag>_*   (copy the summaries you keep into profiles/)
 # 1. bench.py with the CPU baseline (the JSON line)           2. rocprofv3 --kernel-trace --stats of the same command
 # 3./4. rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (no trace domains besides --kernel-trace)
 # The conv plans tuned in step 1 are reloaded (ARSEG_CONV_PLAN_FILE) so that the profiled runs contain no trial launches.
 TAG=${1:-r01}
+CFG=${2:-psp}          # bench.py --config (psp = the headline workload)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 export ARSEG_CONV_PLAN_FILE=$OUT/${TAG}_plans.json
 rm -f $ARSEG_CONV_PLAN_FILE
 cd $R
-python bench.py --steps 9 --warmup 3 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
+python bench.py --config $CFG --steps 9 --warmup 3 2> $OUT/${TAG}_bench.err | tail -1 > $OUT/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline"
+BENCH="python $R/bench.py --config $CFG --steps 3 --warmup 2 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_stats -o s --output-format csv -- $BENCH > $OUT/${TAG}_bench_under_rocprof.json 2> /dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o f --output-format csv -- $BENCH --no-profile > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o w --output-format csv -- $BENCH --no-profile > /dev/null 2>&1
