@@ -454,6 +454,75 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float *__re
             if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
 }
 
+// The same tail for an exact x S bilinear upsample with align_corners=False, S a power of two (BiSeNetOutput's nn.Upsample(x8),
+// model/bisenet.py:215-216): the S output pixels x = S*j + S/2 .. S*j + 3S/2 - 1 of a row all interpolate between the low-resolution
+// columns j and j+1 (src = j + (r + 0.5) / S), so one thread takes such a run, loads its 4 taps once per class and evaluates the S
+// pixels from registers -- 4 loads per class and run instead of 4 S; the per-pixel kernel above issues 76 scattered loads per output
+// pixel at 19 classes and is bound by the texture path's instruction rate (77 us per 1024x2048 frame; this one: memory-side trivial).
+// Identical arithmetic (same taps, same weights from arseg_src_index, same blend expression) and argmax semantics.
+template <int S>
+__global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *__restrict__ logits, const int64_t *__restrict__ label,
+                                                                  int32_t *__restrict__ pred, unsigned long long *__restrict__ hist,
+                                                                  int N, int n_cls, int h, int w, int ignore_label) {
+    __shared__ unsigned int lh[1024];
+    for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    const int H = S * h, W = S * w, runs = w + 1;
+    const long long total = (long long)N * H * runs;
+    const float sc = arseg_resize_scale(h, H, false);          // = 1 / S exactly
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx % runs) - 1, oy = (int)((idx / runs) % H), n = (int)(idx / ((long long)runs * H));
+        int y0, y1; float ly;
+        arseg_src_index(sc, oy, false, h, y0, y1, ly);
+        ly = fminf(fmaxf(ly, 0.f), 1.f);
+        const int x0 = max(j, 0), x1 = min(x0 + 1, w - 1), xs = S * j + S / 2;       // first output column of the run (may be negative for j = -1)
+        float lx[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            int a, b;
+            arseg_src_index(sc, min(max(xs + r, 0), W - 1), false, w, a, b, lx[r]);
+            lx[r] = fminf(fmaxf(lx[r], 0.f), 1.f);
+        }
+        float best[S]; int bi[S]; bool bn[S];
+#pragma unroll
+        for (int r = 0; r < S; ++r) { best[r] = -INFINITY; bi[r] = 0; bn[r] = false; }
+        const float *b = logits + (size_t)n * n_cls * h * w;
+        const size_t o00 = (size_t)y0 * w + x0, o01 = (size_t)y0 * w + x1, o10 = (size_t)y1 * w + x0, o11 = (size_t)y1 * w + x1, cs = (size_t)h * w;
+        for (int k0 = 0; k0 < n_cls; k0 += 4) {          // four classes' taps in flight (a class at a time is bound by the load latency)
+            float t[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float *bk = b + (size_t)min(k0 + u, n_cls - 1) * cs;
+                t[u][0] = bk[o00]; t[u][1] = bk[o01]; t[u][2] = bk[o10]; t[u][3] = bk[o11];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= n_cls) break;
+#pragma unroll
+                for (int r = 0; r < S; ++r) {
+                    const float v = (1.f - ly) * ((1.f - lx[r]) * t[u][0] + lx[r] * t[u][1]) + ly * ((1.f - lx[r]) * t[u][2] + lx[r] * t[u][3]);
+                    if (!bn[r] && (v > best[r] || v != v)) { best[r] = v; bi[r] = k0 + u; bn[r] = v != v; }
+                }
+            }
+        }
+        const long long row = ((long long)n * H + oy) * W;
+#pragma unroll
+        for (int r = 0; r < S; ++r) {
+            const int ox = xs + r;
+            if (ox < 0 || ox >= W) continue;
+            if (pred) pred[row + ox] = bi[r];
+            if (hist && label) {
+                const long long lab = label[row + ox];
+                if (lab != ignore_label && lab >= 0 && lab < n_cls) atomicAdd(&lh[(int)lab * n_cls + bi[r]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    if (hist)
+        for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x)
+            if (lh[i]) atomicAdd(&hist[i], (unsigned long long)lh[i]);
+}
+
 }  // namespace
 
 extern "C" int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream) {
@@ -618,7 +687,17 @@ extern "C" int arseg_argmax_confusion_fwd(const float *logits, const int64_t *la
     ARSEG_CHECK_PTR(logits); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(n_cls); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
     if (n_cls > 32) return ARSEG_EUNSUPPORTED;
     if (!pred && !(hist && label)) return ARSEG_EINVAL;
+    unsigned long long *hh = reinterpret_cast<unsigned long long *>(hist);
+    const int S = H / h;
+    if (!align_corners && S * h == H && S * w == W && (S == 2 || S == 4 || S == 8)) {          // exact power-of-two upsample: one thread per run of S pixels
+        const int g = grid_for((long long)N * H * (w + 1), 4096);
+        hipStream_t st = arseg_stream(stream);
+        if (S == 8) hipLaunchKernelGGL(argmax_confusion_up_kernel<8>, dim3(g), dim3(256), 0, st, logits, label, pred, hh, N, n_cls, h, w, ignore_label);
+        else if (S == 4) hipLaunchKernelGGL(argmax_confusion_up_kernel<4>, dim3(g), dim3(256), 0, st, logits, label, pred, hh, N, n_cls, h, w, ignore_label);
+        else hipLaunchKernelGGL(argmax_confusion_up_kernel<2>, dim3(g), dim3(256), 0, st, logits, label, pred, hh, N, n_cls, h, w, ignore_label);
+        return arseg_launch_status();
+    }
     hipLaunchKernelGGL(argmax_confusion_kernel, dim3(grid_for((long long)N * H * W, 1024)), dim3(256), 0, arseg_stream(stream), logits,
-                       label, pred, reinterpret_cast<unsigned long long *>(hist), N, n_cls, h, w, H, W, ignore_label, align_corners);
+                       label, pred, hh, N, n_cls, h, w, H, W, ignore_label, align_corners);
     return arseg_launch_status();
 }

@@ -433,7 +433,7 @@ def test_argmax_ties_and_nan(dev):
     assert int(hist.sum()) == 8 and torch.equal(hist.cpu()[0], torch.bincount(want.flatten(), minlength=5))
 
 
-@pytest.mark.parametrize("h,w,up", [(16, 24, 8), (5, 7, 8), (9, 11, 2)])
+@pytest.mark.parametrize("h,w,up", [(16, 24, 8), (5, 7, 8), (9, 11, 2), (33, 65, 4), (1, 1, 8), (40, 3, 8), (7, 5, 3)])
 def test_argmax_fused_upsample(dev, h, w, up):
     """f3: head logits -> x`up` bilinear (align_corners=False, BiSeNetOutput.up, model/bisenet.py:215-216) -> argmax -> confusion
     without materialising the full-resolution logits, against torch on the CPU."""
