@@ -54,6 +54,8 @@ PROTOTYPES = {
     "arseg_conv_out_hw": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),
     "arseg_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
+    "arseg_conv2d_find_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
     "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
     "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),

@@ -914,3 +914,79 @@ extern "C" int arseg_pack_dw3x3_host(const float *w, int C, float *out) {
         for (int t = 0; t < 9; ++t) out[(size_t)t * C + c] = w[(size_t)c * 9 + t];
     return ARSEG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// "find": times the launch plans a conv shape admits on the device it will run on and returns the fastest.  The candidate set is
+// every tile_cfg the shape supports (5..12 GEMM tiles, 13..16 patch-resident, 17..19 large f16x3 tiles) x split-K {1,2,3,4,6,8}
+// (K long enough, Cout % 4 == 0, not in batched mode) plus the built-in heuristic (0, 0).  Unlike every other entry point this one
+// SYNCHRONISES the stream (hipEvent timing); it writes `out` (and the workspace) with real results of each candidate.
+namespace {
+struct FindCand { int cfg, sk; };
+int find_candidates(const arseg_conv_desc *d, FindCand *c, int cap) {
+    int n = 0;
+    c[n++] = FindCand{0, 0};
+    if (d->upsample2x) {                       // only the patch-resident plans upsample while they stage
+        for (int cfg = 13; cfg <= 16 && n < cap; ++cfg) c[n++] = FindCand{cfg, 1};
+        return n;
+    }
+    const int ktiles = (d->R * d->S * d->Cin + 31) / 32;
+    for (int cfg = 5; cfg <= 19 && n < cap; ++cfg) {
+        if (cfg >= 13 && cfg <= 16) { c[n++] = FindCand{cfg, 1}; continue; }
+        static const int sks[6] = {1, 2, 3, 4, 6, 8};
+        for (int i = 0; i < 6 && n < cap; ++i) {
+            const int sk = sks[i];
+            if (sk > 1 && (d->batch > 1 || ktiles / sk < 4 || (d->Cout & 3))) continue;
+            c[n++] = FindCand{cfg, sk};
+        }
+    }
+    return n;
+}
+}  // namespace
+
+extern "C" size_t arseg_conv2d_find_workspace_bytes(const arseg_conv_desc *d) {
+    if (!d) return 0;
+    FindCand c[128];
+    const int n = find_candidates(d, c, 128);
+    size_t best = 0;
+    arseg_conv_desc t = *d;
+    for (int i = 0; i < n; ++i) {
+        t.tile_cfg = c[i].cfg; t.split_k = c[i].sk;
+        const size_t b = arseg_conv2d_workspace_bytes(&t);
+        if (b > best) best = b;
+    }
+    return best;
+}
+
+extern "C" int arseg_conv2d_find(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale, const float *bias,
+                                 const float *residual, float *out, void *workspace, size_t workspace_bytes, int reps, int *tile_cfg,
+                                 int *split_k, float *best_us, arseg_stream_t stream) {
+    if (!d || !tile_cfg || !split_k) return ARSEG_EINVAL;
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(w_packed); ARSEG_CHECK_PTR(out);
+    if (reps <= 0) reps = 3;
+    hipStream_t hs = arseg_stream(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess) return ARSEG_EINVAL;
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return ARSEG_EINVAL; }
+    FindCand c[128];
+    const int n = find_candidates(d, c, 128);
+    arseg_conv_desc t = *d;
+    float best = -1.0f;
+    int first_err = ARSEG_EUNSUPPORTED;
+    for (int i = 0; i < n; ++i) {
+        t.tile_cfg = c[i].cfg; t.split_k = c[i].sk;
+        if (arseg_conv2d_workspace_bytes(&t) > workspace_bytes) continue;
+        int st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);      // warm
+        if (st != ARSEG_OK) { if (i == 0) first_err = st; continue; }
+        (void)hipEventRecord(e0, hs);
+        for (int r = 0; r < reps; ++r) st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(e1, hs);
+        if (hipEventSynchronize(e1) != hipSuccess) { st = (int)hipGetLastError(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st ? st : ARSEG_EINVAL; }
+        float ms = 0.0f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (st == ARSEG_OK && (best < 0.0f || ms < best)) { best = ms; *tile_cfg = c[i].cfg; *split_k = c[i].sk; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (best < 0.0f) return first_err;          // nothing could be launched (e.g. the 2 GiB limit of the 32-bit buffer offsets)
+    if (best_us) *best_us = best * 1000.0f / (float)reps;
+    return ARSEG_OK;
+}

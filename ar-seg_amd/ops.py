@@ -451,6 +451,7 @@ class _PlanCache(dict):
 
 
 _conv_plans = _PlanCache()
+_NATIVE_FIND = os.environ.get("ARSEG_CONV_FIND", "native") != "python"      # "python": time the candidates from the host loop below instead
 _PATCH_CFGS = (13, 14, 15, 16)      # arseg_conv_desc.tile_cfg of the patch-resident 3x3 kernel (the only direct plans with a fused x2 upsample)
 
 
@@ -547,6 +548,21 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     def launch_wino(record=True):
         _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
 
+    def find_native():
+        """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
+        fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
+        xin = x
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        if x_low is not None:
+            xin, d.upsample2x, d.in_ld = x_low, 1, _nhwc_ld(x_low)
+        nbytes = lib.arseg_conv2d_find_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, out.device) if nbytes else None
+        cfg, sk, us = ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+        st = lib.arseg_conv2d_find(ctypes.byref(d), _ptr(xin), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws),
+                                   nbytes, 3, ctypes.byref(cfg), ctypes.byref(sk), ctypes.byref(us), _stream())
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        return (cfg.value, sk.value) if st == _lib.ARSEG_OK else None
+
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
         key = (dev.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
         wino_ok = getattr(pc, "wino_u", None) is not None and _WINOGRAD
@@ -554,7 +570,9 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         if plan == "wino" and not wino_ok:                      # a persisted Winograd plan with ARSEG_CONV_WINOGRAD=0: re-tune
             plan = None
         if plan is None:
-            plan = _tune_conv(launch, pc, N * Ho * Wo)
+            plan = find_native() if _NATIVE_FIND else None
+            if plan is None:
+                plan = _tune_conv(launch, pc, N * Ho * Wo)
             if plan is None:
                 # nothing could be launched.  The one shape-independent cause is the 2 GiB limit of the kernels' 32-bit buffer
                 # offsets on a large batch: split the batch (as creff does) instead of caching a plan that never ran.

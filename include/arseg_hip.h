@@ -187,6 +187,18 @@ int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const float *w_p
                      const float *bias, const float *residual, float *out, void *workspace, size_t workspace_bytes,
                      arseg_stream_t stream);
 
+/* Plan selection ("find", what MIOpen calls miopenFindConvolutionForwardAlgorithm; the reference gets it implicitly from
+ * torch.backends.cudnn.benchmark, train.py / evaluation.py): runs every launch plan the shape admits -- all tile_cfg it supports x
+ * split-K {1,2,3,4,6,8}, plus the built-in heuristic (0,0) -- `reps` times each (<= 0: 3) on the caller's buffers, times them with
+ * HIP events and returns the fastest as (*tile_cfg, *split_k) for arseg_conv_desc, its time in *best_us (may be NULL).
+ * d->tile_cfg / d->split_k are ignored.  `workspace` should hold arseg_conv2d_find_workspace_bytes(d) bytes (candidates needing more
+ * than workspace_bytes are skipped).  The ONLY entry point that synchronises the stream; `out` holds a valid result afterwards.
+ * Returns the error of the heuristic plan if no candidate could be launched. */
+size_t arseg_conv2d_find_workspace_bytes(const arseg_conv_desc *d);
+int arseg_conv2d_find(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale, const float *bias,
+                      const float *residual, float *out, void *workspace, size_t workspace_bytes, int reps, int *tile_cfg,
+                      int *split_k, float *best_us, arseg_stream_t stream);
+
 /* Winograd F(4x4,3x3) path for 3x3 stride-1 convs with pad == dil (model/extractors.py:30-32 conv3x3, model/pspnet.py:38):
  *   V[36][T][Cin]  = arseg_wino43_input_fwd(in NHWC)          T = arseg_wino43_tiles(N,H,W,dil)
  *   M[36][T][Cout] = 36 GEMMs V[k] x U[k]^T                   arseg_conv2d_fwd in batched mode (batch = 36, 1x1)
