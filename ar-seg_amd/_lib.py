@@ -67,7 +67,8 @@ PROTOTYPES = {
     "arseg_pack_dw3x3_host": (c_int, [_P, c_int, _P]),
     "arseg_packed_k16": (c_int, [c_int, c_int, c_int]),
     "arseg_pack_conv_weight16_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "arseg_conv2d16_fwd": (c_int, [POINTER(ConvDesc), c_int, _P, _P, _P, _P, _P, _P, _STREAM]),
+    "arseg_conv2d16_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "arseg_conv2d16_fwd": (c_int, [POINTER(ConvDesc), c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
     "arseg_frame_to_nhwc8_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_maxpool3x3s2_16_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_global_mean16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -32,6 +32,8 @@ struct Conv16Params {
     float slope;
     int tiles_co, tiles_px;
     unsigned in_bytes, w_bytes;
+    int nsplit, kt_per_split;        // split-K: blockIdx.y = K slice, fp32 partial sums to `ws` [nsplit][M][Cout], epilogue in the reduce kernel
+    float *ws;
 };
 
 constexpr int PIX_T = 128, KPAD = 64;                  // Kpad16 is a multiple of 64 (both K steps divide it)
@@ -137,12 +139,12 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    const int ktiles = p.Kpad / BK;
+    const int kt0 = blockIdx.y * p.kt_per_split, ktiles = min(p.Kpad / BK, kt0 + p.kt_per_split);      // this K slice (all of K without split-K)
     Regs rg;
-    load(0, rg);
-    store(0, rg);
+    load(kt0, rg);
+    store(kt0 & 1, rg);
     __syncthreads();
-    for (int kt = 0; kt < ktiles; ++kt) {
+    for (int kt = kt0; kt < ktiles; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < ktiles) load(kt + 1, rg);
 #pragma unroll
@@ -182,6 +184,14 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
         for (int it = tid; it < ITEMS; it += 256) {
             const int px = it / (CO_T / 8), c8 = it - px * (CO_T / 8);
             const int m = px0 + ps * PPX + px, co = co0 + c8 * 8;
+            if (p.nsplit > 1) {                       // split-K: raw fp32 partial sums, the epilogue runs in conv16_splitk_reduce_kernel
+                if (m < p.M && co < p.Cout) {
+                    float *dst = p.ws + ((size_t)blockIdx.y * p.M + m) * p.Cout + co;
+                    *reinterpret_cast<f32x4 *>(dst) = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8);
+                    *reinterpret_cast<f32x4 *>(dst + 4) = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8 + 4);
+                }
+                continue;
+            }
             if (m < p.M && co < p.Cout) {
                 float v[8];
                 const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8), v1 = *reinterpret_cast<const f32x4 *>(Ot + px * OLD + c8 * 8 + 4);
@@ -225,14 +235,51 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     }
 }
 
+// sums the split-K partials in slice order and applies the epilogue (scale, bias, residual, activation, one rounding to 16 bits);
+// 8 channels per thread (Cout % 8 == 0 with split-K)
+template <bool BF>
+__global__ __launch_bounds__(256) void conv16_splitk_reduce_kernel(const Conv16Params p) {
+    const int c8n = p.Cout >> 3;
+    const long long total = (long long)p.M * c8n;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(idx / c8n), co = (int)(idx - (long long)m * c8n) * 8;
+        const float *src = p.ws + (size_t)m * p.Cout + co;
+        f32x4 a = *reinterpret_cast<const f32x4 *>(src), b = *reinterpret_cast<const f32x4 *>(src + 4);
+        for (int z = 1; z < p.nsplit; ++z) {
+            a += *reinterpret_cast<const f32x4 *>(src + (size_t)z * p.M * p.Cout);
+            b += *reinterpret_cast<const f32x4 *>(src + (size_t)z * p.M * p.Cout + 4);
+        }
+        u32x4 rres = {0, 0, 0, 0};
+        if (p.res) rres = *reinterpret_cast<const u32x4 *>(p.res + (size_t)m * p.res_ld + co);
+        uint16_t o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = (e < 4 ? a[e] : b[e - 4]) * (p.scale ? p.scale[co + e] : 1.0f) + (p.bias ? p.bias[co + e] : 0.0f);
+            if (p.res) x += arseg_h2f<BF>((uint16_t)((e & 1) ? rres[e >> 1] >> 16 : rres[e >> 1] & 0xffffu));
+            o[e] = arseg_f2h<BF>(act_apply(x, p.act, p.slope));
+        }
+        *reinterpret_cast<u32x4 *>(p.out + (size_t)m * p.out_ld + co) =
+            u32x4{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16), o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16)};
+    }
+}
+
 template <bool BF, int CO_T, int BK>
 int launch(const Conv16Params &p, hipStream_t st) {
     const size_t stage = (size_t)2 * (CO_T + PIX_T) * (BK + 8) * 2, epi = (size_t)(CO_T == 128 ? 64 : 128) * (CO_T + 4) * 4;
     const size_t smem = stage > epi ? stage : epi;
     static ArsegSmemAttr attr;
     if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_kernel<BF, CO_T, BK>), smem)) return e;
-    hipLaunchKernelGGL((conv16_kernel<BF, CO_T, BK>), dim3(p.tiles_co * p.tiles_px), dim3(256), smem, st, p);
-    return arseg_launch_status();
+    Conv16Params q = p;
+    q.kt_per_split = arseg_cdiv(p.Kpad / BK, p.nsplit);
+    q.nsplit = arseg_cdiv(p.Kpad / BK, q.kt_per_split);            // no empty slices
+    hipLaunchKernelGGL((conv16_kernel<BF, CO_T, BK>), dim3(p.tiles_co * p.tiles_px, q.nsplit), dim3(256), smem, st, q);
+    if (int e = arseg_launch_status()) return e;
+    if (q.nsplit > 1) {
+        long long blocks = ((long long)p.M * (p.Cout >> 3) + 255) / 256;
+        hipLaunchKernelGGL((conv16_splitk_reduce_kernel<BF>), dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, st, q);
+        return arseg_launch_status();
+    }
+    return ARSEG_OK;
 }
 template <bool BF>
 int launch_cfg(const Conv16Params &p, bool wide, bool deep, hipStream_t st) {
@@ -242,8 +289,40 @@ int launch_cfg(const Conv16Params &p, bool wide, bool deep, hipStream_t st) {
 
 }  // namespace
 
+namespace {
+// split-K slices of a launch: explicit (desc.split_k >= 1) or, with 0, chosen so that a launch whose tiles do not fill the chip and
+// whose K loop is long gets ~2 workgroups per CU (the 16x32-map layers of BiSeNet-18: 176 tiles, K = 4608)
+int conv16_nsplit(const arseg_conv_desc *d, long long M, int Kpad, int co_t) {
+    if (d->Cout & 7) return 1;
+    const int kt64 = Kpad / 64;
+    int ns = d->split_k;
+    if (ns <= 0) {
+        const long long tiles = (long long)arseg_cdiv(d->Cout, co_t) * arseg_cdiv(M, PIX_T);
+        ns = 1;
+        while (tiles * ns < 384 && ns < 8 && kt64 / (ns * 2) >= 6) ns *= 2;
+    }
+    if (ns > kt64) ns = kt64;
+    return ns < 1 ? 1 : ns;
+}
+bool conv16_wide(const arseg_conv_desc *d, long long M) {
+    const int cfg = d->tile_cfg;
+    if (cfg == 0) return d->Cout > 64 && (long long)arseg_cdiv(d->Cout, 128) * arseg_cdiv(M, PIX_T) >= 512;
+    return cfg == 2 || cfg == 4;
+}
+}  // namespace
+
+extern "C" size_t arseg_conv2d16_workspace_bytes(const arseg_conv_desc *d) {
+    int Ho, Wo;
+    if (!d || arseg_conv_out_hw(d, &Ho, &Wo) != ARSEG_OK) return 0;
+    const long long M = (long long)d->N * Ho * Wo;
+    const int Kpad = (d->R * d->S * d->Cin + KPAD - 1) / KPAD * KPAD;
+    const int ns = conv16_nsplit(d, M, Kpad, conv16_wide(d, M) ? 128 : 64);
+    return ns > 1 ? (size_t)ns * M * d->Cout * sizeof(float) : 0;
+}
+
 extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,
-                                  const float *bias, const void *residual, void *out, arseg_stream_t stream) {
+                                  const float *bias, const void *residual, void *out, void *workspace, size_t workspace_bytes,
+                                  arseg_stream_t stream) {
     if (!d) return ARSEG_EINVAL;
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(w_packed16); ARSEG_CHECK_PTR(out);
     ARSEG_CHECK_POS(d->N); ARSEG_CHECK_POS(d->H); ARSEG_CHECK_POS(d->W); ARSEG_CHECK_POS(d->Cin); ARSEG_CHECK_POS(d->Cout);
@@ -268,13 +347,16 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     // tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with K step 64
     const int cfg = d->tile_cfg;
     if (cfg < 0 || cfg > 4) return ARSEG_EINVAL;
-    bool wide = cfg == 2 || cfg == 4, deep = cfg >= 3;
-    if (cfg == 0) {
-        // 128-channel tiles when they still give every CU a few workgroups, K step 64 (half the barriers, 74 KB of LDS) for long K loops
-        wide = d->Cout > 64 && (long long)arseg_cdiv(d->Cout, 128) * arseg_cdiv(M, PIX_T) >= 512;
-        deep = p.K >= 512;
-    }
+    // 128-channel tiles when they still give every CU a few workgroups, K step 64 (half the barriers, 74 KB of LDS) for long K loops
+    const bool wide = conv16_wide(d, M), deep = cfg == 0 ? p.K >= 512 : cfg >= 3;
     const int co_t = wide ? 128 : 64;
+    if (d->split_k < 0) return ARSEG_EINVAL;
+    p.nsplit = conv16_nsplit(d, M, p.Kpad, co_t);
+    p.kt_per_split = 0; p.ws = reinterpret_cast<float *>(workspace);
+    if (p.nsplit > 1) {
+        if (!workspace || workspace_bytes < (size_t)p.nsplit * M * d->Cout * sizeof(float)) return ARSEG_EWORKSPACE;
+        if (!ARSEG_ALIGNED16(workspace)) return ARSEG_EINVAL;
+    }
     p.tiles_co = arseg_cdiv(d->Cout, co_t); p.tiles_px = arseg_cdiv(M, PIX_T);
     hipStream_t st = arseg_stream(stream);
     return dtype == ARSEG_DT_BF16 ? launch_cfg<true>(p, wide, deep, st) : launch_cfg<false>(p, wide, deep, st);

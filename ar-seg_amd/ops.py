@@ -483,7 +483,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     the Winograd route applies it inside its input transform, the patch-resident direct plans while they stage their input patch;
     the GEMM-tile plans materialise it first."""
     if is16(x):
-        return _conv2d16(x, pc, residual, out, up2, tile_cfg)
+        return _conv2d16(x, pc, residual, out, up2, tile_cfg, split_k)
     _need_gpu(x, residual, out)
     x_low = None
     if up2:
@@ -600,7 +600,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     return out
 
 
-def _conv2d16(x, pc, residual, out, up2, tile_cfg=0):
+def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
     """conv2d on the 16-bit storage path: one MFMA per product (arseg_conv2d16_fwd), fp32 epilogue (pc.scale / pc.bias)."""
     dt = _need_gpu16(x, residual, out)
     if up2:
@@ -631,8 +631,33 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0):
         if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
             raise _lib.ArsegError("residual shape mismatch")
         d.res_ld = _nhwc_ld(residual)
-    _launch("conv2d", lib.arseg_conv2d16_fwd, ctypes.byref(d), dt, _ptr(x), _ptr(w16), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out),
-            _stream(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
+    d.split_k = split_k
+
+    def args():
+        nbytes = lib.arseg_conv2d16_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, x.device) if nbytes else None
+        return (ctypes.byref(d), dt, _ptr(x), _ptr(w16), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+
+    if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:      # per-shape plan: tile / K-step variants x split-K timed once on the device
+        key = ("conv16", x.device.index, dt, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil)
+        plan = _conv_plans.get(key)
+        if plan is None:
+            best_t = float("inf")
+            ktiles = (pc.R * pc.S * Cin + 63) // 64
+            for cfg in (0, 1, 2, 3, 4):
+                for sk in (0, 1, 2, 4, 8):
+                    if sk > 1 and (ktiles // sk < 3 or pc.cout % 8):
+                        continue
+                    d.tile_cfg, d.split_k = cfg, sk
+                    try:
+                        t = _time(lambda: check(lib.arseg_conv2d16_fwd(*args()), "conv2d16"))
+                    except _lib.ArsegError:
+                        continue
+                    if t < best_t:
+                        plan, best_t = (cfg, sk), t
+            _conv_plans[key] = plan = plan or (0, 0)
+        d.tile_cfg, d.split_k = plan
+    _launch("conv2d", lib.arseg_conv2d16_fwd, *args(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
     return out
 
 

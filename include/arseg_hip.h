@@ -287,12 +287,17 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  * rounded to 16 bits once, at the store.  Cin % 8 == 0 (frames are ingested as NHWC8), in_ld / out_ld / res_ld % 8 == 0.
  *   arseg_pack_conv_weight16_host: OIHW fp32 -> [Cout][Kpad16] 16-bit with k = (r*S+s)*Cin_pad + ci, Kpad16 = arseg_packed_k16(...)
  *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with
- *                       K step 64; split_k / batch unused)
+ *                       K step 64; split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
+ *                       layers of BiSeNet-18 --, >= 1 explicit; deterministic: fp32 partial sums in `workspace`
+ *                       (arseg_conv2d16_workspace_bytes(desc) bytes, 0 without split-K), summed in slice order by a second kernel that
+ *                       applies the epilogue; split-K needs Cout % 8 == 0, otherwise one slice.  batch unused)
  * ------------------------------------------------------------------------------------------- */
 int arseg_packed_k16(int Cin_pad, int R, int S);
 int arseg_pack_conv_weight16_host(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host);
+size_t arseg_conv2d16_workspace_bytes(const arseg_conv_desc *d);
 int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,
-                       const float *bias, const void *residual, void *out, arseg_stream_t stream);
+                       const float *bias, const void *residual, void *out, void *workspace, size_t workspace_bytes,
+                       arseg_stream_t stream);
 /* The small layers on 16-bit NHWC tensors (C, ld % 8 == 0), same arithmetic as their fp32 counterparts above, fp32 inside:
  *   frame ingest: NCHW fp32 RGB -> NHWC8 (channels 3..7 zero) + bilinear align_corners=True downscale      evaluation.py:186-188
  *   maxpool 3x3 s2 p1; torch.mean(x,(2,3)) -> [N][C]; resize (nearest | bilinear, align_corners on / off); x*scale[n,c] (+add_full) (+add_vec[n,c])

@@ -88,6 +88,11 @@ def test_conv2d16(dev, case, dtype):
         got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg)
         assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
         close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+    if Cout % 8 == 0 and k * k * Cin >= 256:        # split-K: fp32 partial sums + the epilogue in the reduce kernel; deterministic
+        for cfg, sk in ((1, 2), (3, 3), (4, 8)):
+            got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg, split_k=sk)
+            close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+            assert torch.equal(got, ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg, split_k=sk))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
