@@ -32,6 +32,7 @@ struct Conv16Params {
     float slope;
     int tiles_co, tiles_px;
     unsigned in_bytes, w_bytes;
+    int patch_tw, patch_l2tw, tiles_m;      // patch-resident 3x3 kernel: tile width (a power of two), its log2, pixel tiles
     int nsplit, kt_per_split;        // split-K: blockIdx.y = K slice, fp32 partial sums to `ws` [nsplit][M][Cout], epilogue in the reduce kernel
     float *ws;
 };
@@ -235,6 +236,216 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Patch-resident kernel for 3x3 stride-1 pad == dil convs with Cin % 64 == 0 (the 16-bit twin of conv3x3_patch_kernel in
+// conv_igemm.hip): a workgroup owns a TH x TW pixel tile of ONE image and BN output channels and, per 64-channel chunk, stages the
+// (TH+2d) x (TW+2d) input patch once (128 bytes per pixel); the nine taps are A-fragment address offsets into it.  Only the weight tile
+// (BN x 64 halves) streams per tap, requested two taps ahead (two register stages + LDS double buffer).  The implicit-GEMM kernel
+// above re-fetches the activation slice of every tap from L2 and has 16 MFMAs per wave between barriers; here the activations are
+// read from L2 once instead of nine times.  D[pixel][co] (A = pixels, B = weights), C/D layout: co = lane & 31.
+template <bool BF, int BN, int WM>      // WM wave rows of 64 output pixels each: BM = 64*WM pixels, 2*WM waves
+__global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv16_patch_kernel(const Conv16Params p) {
+    constexpr int ROWB = 144;                          // bytes per LDS row: 64 halves + pad (conflict-free b128 reads)
+    constexpr int NT = 128 * WM, BM = 64 * WM;
+    constexpr int TN = BN / 64, TM = 2, RB = (BN * 8 + NT - 1) / NT, RPB = NT / 8;
+    constexpr int MAXI = WM == 2 ? 9 : 7;              // patch items (pixel, 16-byte piece) per thread: <= 288 / 448 pixels
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int TW = p.patch_tw, log2TW = p.patch_l2tw;
+    const int TH = BM >> log2TW, d = p.dil, PW = TW + 2 * d, PH = TH + 2 * d, npx = PW * PH;
+    unsigned char *Ps = smem;                                                  // [npx][ROWB]
+    unsigned char *Bs = Ps + ((npx * ROWB + 255) & ~255);                        // [2][BN][ROWB]
+
+    const int tiles_x = (p.Wo + TW - 1) >> log2TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nblk = p.tiles_m * p.tiles_co;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / p.tiles_co, tile_n = bid - tile_m * p.tiles_co;
+    const int img = tile_m / (tiles_x * tiles_y), trem = tile_m - img * (tiles_x * tiles_y);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW, n0 = tile_n * BN;
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.w), 0, (int)p.w_bytes, 0x00020000);
+    const int tid = threadIdx.x;
+
+    unsigned poff[MAXI];                               // item i = (pixel i/8, piece i%8): global byte offset without the chunk term, or OOB
+#pragma unroll
+    for (int it = 0; it < MAXI; ++it) {
+        const int i = tid + it * NT, px = i >> 3, py = px / PW, pxx = px - py * PW;
+        const int gy = ty0 - d + py, gx = tx0 - d + pxx;
+        const bool ok = px < npx && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        poff[it] = ok ? (unsigned)((((img * p.H + gy) * p.W + gx) * p.in_ld) * 2 + (i & 7) * 16) : OOB;
+    }
+    const int chunk = tid & 7, row0 = tid >> 3;
+    unsigned woff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + row0 + RPB * i;
+        woff[i] = (n < p.Cout && row0 + RPB * i < BN) ? (unsigned)(n * p.Kpad + chunk * 8) * 2u : OOB;
+    }
+    const int nchunk = p.Cin >> 6;
+
+    struct BRegs { u32x4 v[RB]; };
+    u32x4 rp[MAXI];
+    auto load_patch = [&](int ck) {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) rp[it] = __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, poff[it] + (unsigned)(ck * 128), 0, 0);
+    };
+    auto store_patch = [&]() {
+#pragma unroll
+        for (int it = 0; it < MAXI; ++it) {
+            const int i = tid + it * NT, px = i >> 3;
+            if (px < npx) *reinterpret_cast<u32x4 *>(Ps + px * ROWB + (i & 7) * 16) = rp[it];
+        }
+    };
+    auto load_b = [&](int ck, int tap, BRegs &r) {
+        const unsigned kt = (unsigned)(tap * nchunk + ck) * 128u;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) r.v[i] = __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, woff[i] + kt, 0, 0);
+    };
+    auto store_b = [&](int buf, const BRegs &r) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            if (row0 + RPB * i < BN) *reinterpret_cast<u32x4 *>(Bs + (buf * BN + row0 + RPB * i) * ROWB + chunk * 16) = r.v[i];
+    };
+
+    const int wave = tid >> 6, lane = tid & 63, wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+    int arow[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = wm * 64 + tm * 32 + li, ty = m >> log2TW, tx = m & (TW - 1);
+        arow[tm] = (ty * PW + tx) * ROWB + lh * 16;
+    }
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    const int nsteps = nchunk * 9;                     // K steps s = (chunk ck, tap): s = 9*ck + tap
+    BRegs r0, r1;
+    load_patch(0);
+    load_b(0, 0, r0);
+    store_patch();
+    store_b(0, r0);
+    if (nsteps > 1) load_b(0, 1, r0);
+    __syncthreads();
+    int cur = 0, ck = 0, tap = 0;              // of the step being computed
+    int ck2 = 0, tap2 = 2;                     // of the step two ahead
+    auto step = [&](int s_, BRegs &ld, BRegs &st) {
+        if (s_ + 2 < nsteps) load_b(ck2, tap2, ld);
+        if (tap == 0 && ck + 1 < nchunk) load_patch(ck + 1);
+        const int r3 = (tap * 11) >> 5, s3 = tap - r3 * 3;                 // tap = 3*r3 + s3
+        const int toff = (r3 * d * PW + s3 * d) * ROWB;
+        const unsigned char *bh = Bs + (cur * BN + wn * (BN / 2) + li) * ROWB + lh * 16;
+        u32x4 fa[4][TM], fb[4][TN];                  // all fragments of the tap first, then the MFMAs back to back
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int t = 0; t < TM; ++t) fa[ks][t] = *reinterpret_cast<const u32x4 *>(Ps + arow[t] + toff + ks * 32);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) fb[ks][t] = *reinterpret_cast<const u32x4 *>(bh + t * 32 * ROWB + ks * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) acc[tm][tn] = mfma16<BF>(fa[ks][tm], fb[ks][tn], acc[tm][tn]);
+        if (s_ + 1 < nsteps) store_b(cur ^ 1, st);
+        __syncthreads();
+        cur ^= 1;
+        if (tap == 8 && ck + 1 < nchunk) {     // everybody is past the last tap of this chunk: the patch may be replaced
+            store_patch();
+            __syncthreads();
+        }
+        if (++tap == 9) { tap = 0; ++ck; }
+        if (++tap2 == 9) { tap2 = 0; ++ck2; }
+    };
+#pragma unroll 1
+    for (int s_ = 0; s_ < nsteps; s_ += 2) {
+        step(s_, r1, r0);
+        if (s_ + 1 < nsteps) step(s_ + 1, r0, r1);
+    }
+
+    // epilogue through LDS (the patch and the weight tiles are dead: the last step ended with a barrier): 128 pixels at a time the fp32
+    // accumulators are laid out [pixel][co] so that scale / bias / residual / activation run on 8 consecutive channels and the store is a
+    // 16-byte vector of an NHWC row.  C/D layout of the 32x32 MFMA: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).
+    float *Ot = reinterpret_cast<float *>(smem);
+    constexpr int OLD = BN + 4;
+#pragma unroll 1
+    for (int half = 0; half < BM / 128; ++half) {
+        if ((wm >> 1) == half) {
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int pl = (wm & 1) * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        Ot[pl * OLD + wn * (BN / 2) + tn * 32 + li] = acc[tm][tn][r];
+                    }
+        }
+        __syncthreads();
+        for (int it = tid; it < 128 * (BN / 8); it += NT) {
+            const int pl = it / (BN / 8), c8 = it - pl * (BN / 8);
+            const int ml = half * 128 + pl, oy = ty0 + (ml >> log2TW), ox = tx0 + (ml & (TW - 1)), co = n0 + c8 * 8;
+            if (oy >= p.Ho || ox >= p.Wo || co >= p.Cout) continue;
+            const size_t m = ((size_t)img * p.Ho + oy) * p.Wo + ox;
+            const f32x4 v0 = *reinterpret_cast<const f32x4 *>(Ot + pl * OLD + c8 * 8), v1 = *reinterpret_cast<const f32x4 *>(Ot + pl * OLD + c8 * 8 + 4);
+            const int nco = min(8, p.Cout - co);
+            uint16_t o[8];
+            if (nco == 8) {
+                const f32x4 s0 = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + co) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 s1 = p.scale ? *reinterpret_cast<const f32x4 *>(p.scale + co + 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 b1 = p.bias ? *reinterpret_cast<const f32x4 *>(p.bias + co + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                u32x4 rres = {0, 0, 0, 0};
+                if (p.res) rres = *reinterpret_cast<const u32x4 *>(p.res + m * p.res_ld + co);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float x = (e < 4 ? v0[e] : v1[e - 4]) * (e < 4 ? s0[e] : s1[e - 4]) + (e < 4 ? b0[e] : b1[e - 4]);
+                    if (p.res) x += arseg_h2f<BF>((uint16_t)((e & 1) ? rres[e >> 1] >> 16 : rres[e >> 1] & 0xffffu));
+                    o[e] = arseg_f2h<BF>(act_apply(x, p.act, p.slope));
+                }
+                *reinterpret_cast<u32x4 *>(p.out + m * p.out_ld + co) =
+                    u32x4{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16), o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16)};
+            } else {
+                for (int e = 0; e < nco; ++e) {
+                    float x = (e < 4 ? v0[e] : v1[e - 4]) * (p.scale ? p.scale[co + e] : 1.0f) + (p.bias ? p.bias[co + e] : 0.0f);
+                    if (p.res) x += arseg_h2f<BF>(p.res[m * p.res_ld + co + e]);
+                    p.out[m * p.out_ld + co + e] = arseg_f2h<BF>(act_apply(x, p.act, p.slope));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <bool BF, int BN, int WM>
+int launch_patch16(const Conv16Params &p, hipStream_t st) {
+    const int th = 64 * WM / p.patch_tw, npx = (th + 2 * p.dil) * (p.patch_tw + 2 * p.dil);
+    const size_t stage = (size_t)((npx * 144 + 255) & ~255) + (size_t)2 * BN * 144, epi = (size_t)128 * (BN + 4) * 4;
+    const size_t smem = stage > epi ? stage : epi;
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_patch_kernel<BF, BN, WM>), smem)) return e;
+    hipLaunchKernelGGL((conv16_patch_kernel<BF, BN, WM>), dim3(p.tiles_m * p.tiles_co), dim3(128 * WM), smem, st, p);
+    return arseg_launch_status();
+}
+template <bool BF>
+int launch_patch16_cfg(const Conv16Params &p, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 5: return launch_patch16<BF, 64, 2>(p, st);
+        case 6: return launch_patch16<BF, 128, 2>(p, st);
+        case 7: return launch_patch16<BF, 64, 4>(p, st);
+        default: return launch_patch16<BF, 128, 4>(p, st);
+    }
+}
+
 // sums the split-K partials in slice order and applies the epilogue (scale, bias, residual, activation, one rounding to 16 bits);
 // 8 channels per thread (Cout % 8 == 0 with split-K)
 template <bool BF>
@@ -293,7 +504,7 @@ namespace {
 // split-K slices of a launch: explicit (desc.split_k >= 1) or, with 0, chosen so that a launch whose tiles do not fill the chip and
 // whose K loop is long gets ~2 workgroups per CU (the 16x32-map layers of BiSeNet-18: 176 tiles, K = 4608)
 int conv16_nsplit(const arseg_conv_desc *d, long long M, int Kpad, int co_t) {
-    if (d->Cout & 7) return 1;
+    if ((d->Cout & 7) || d->tile_cfg >= 5) return 1;          // (the patch-resident plans have no split-K)
     const int kt64 = Kpad / 64;
     int ns = d->split_k;
     if (ns <= 0) {
@@ -346,7 +557,20 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     p.M = (int)M; p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     // tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with K step 64
     const int cfg = d->tile_cfg;
-    if (cfg < 0 || cfg > 4) return ARSEG_EINVAL;
+    if (cfg < 0 || cfg > 8) return ARSEG_EINVAL;
+    if (cfg >= 5) {          // patch-resident 3x3 kernel: 5 / 6 = 128-pixel tiles with 64 / 128 output channels, 7 / 8 = 256-pixel tiles
+        if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || (d->Cin & 63) || d->split_k > 1) return ARSEG_EUNSUPPORTED;
+        const int bm = cfg >= 7 ? 256 : 128;
+        const int tw = Wo >= 48 ? 64 : (Wo >= 24 ? 32 : 16), th = bm / tw;
+        if ((th + 2 * d->dil) * (tw + 2 * d->dil) > (bm == 128 ? 288 : 448)) return ARSEG_EUNSUPPORTED;
+        p.patch_tw = tw; p.patch_l2tw = tw == 64 ? 6 : (tw == 32 ? 5 : 4);
+        p.tiles_m = d->N * arseg_cdiv(Ho, th) * arseg_cdiv(Wo, tw);
+        p.tiles_co = arseg_cdiv(d->Cout, (cfg & 1) ? 64 : 128); p.tiles_px = 0;
+        p.nsplit = 1; p.kt_per_split = 0; p.ws = nullptr;
+        hipStream_t st = arseg_stream(stream);
+        return dtype == ARSEG_DT_BF16 ? launch_patch16_cfg<true>(p, cfg, st) : launch_patch16_cfg<false>(p, cfg, st);
+    }
+    p.patch_tw = 0; p.patch_l2tw = 0; p.tiles_m = 0;
     // 128-channel tiles when they still give every CU a few workgroups, K step 64 (half the barriers, 74 KB of LDS) for long K loops
     const bool wide = conv16_wide(d, M), deep = cfg == 0 ? p.K >= 512 : cfg >= 3;
     const int co_t = wide ? 128 : 64;

@@ -287,7 +287,9 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  * rounded to 16 bits once, at the store.  Cin % 8 == 0 (frames are ingested as NHWC8), in_ld / out_ld / res_ld % 8 == 0.
  *   arseg_pack_conv_weight16_host: OIHW fp32 -> [Cout][Kpad16] 16-bit with k = (r*S+s)*Cin_pad + ci, Kpad16 = arseg_packed_k16(...)
  *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with
- *                       K step 64; split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
+ *                       K step 64; 5..8 = patch-resident kernel for 3x3 stride-1 pad == dil convs with Cin % 64 == 0 (the input patch of a
+ *                       128- (5, 6) / 256-pixel (7, 8) tile stays in LDS for all nine taps, 64 / 128 output channels; no split-K;
+ *                       ARSEG_EUNSUPPORTED for other shapes); split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
  *                       layers of BiSeNet-18 --, >= 1 explicit; deterministic: fp32 partial sums in `workspace`
  *                       (arseg_conv2d16_workspace_bytes(desc) bytes, 0 without split-K), summed in slice order by a second kernel that
  *                       applies the epilogue; split-K needs Cout % 8 == 0, otherwise one slice.  batch unused)

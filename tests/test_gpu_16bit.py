@@ -47,6 +47,8 @@ CASES = [
     (3, 1, 1, 128, 128, 1, 1, 0, 1, "sigmoid", True, False, False),  # attention vector (ARM / FFM)
     (1, 16, 24, 256, 256, 3, 1, 1, 1, "relu", True, False, False),   # feat_conv_out
     (1, 30, 40, 64, 72, 3, 1, 2, 2, "prelu", True, True, True),      # dilation, Cout not a multiple of the tile, bias
+    (3, 37, 70, 128, 128, 3, 1, 1, 1, "relu", True, False, True),    # two 64-channel chunks, ragged 64-wide patch tiles, batch
+    (1, 9, 150, 64, 192, 3, 1, 1, 1, "none", False, True, False),    # wide and flat, three 64-channel output tiles
 ]
 
 
@@ -88,6 +90,10 @@ def test_conv2d16(dev, case, dtype):
         got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg)
         assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
         close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+    if k == 3 and stride == 1 and pad == dil and Cin % 64 == 0:          # patch-resident plans
+        for cfg in (5, 6, 7, 8):
+            got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg)
+            close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
     if Cout % 8 == 0 and k * k * Cin >= 256:        # split-K: fp32 partial sums + the epilogue in the reduce kernel; deterministic
         for cfg, sk in ((1, 2), (3, 3), (4, 8)):
             got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg, split_k=sk)
