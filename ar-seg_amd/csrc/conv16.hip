@@ -446,6 +446,112 @@ int launch_patch16_cfg(const Conv16Params &p, int cfg, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Stem kernel: 7x7 stride-2 pad-3 conv of an NHWC8 frame to 64 channels (+ folded BN + activation) -- conv1 of the ResNet-18 context
+// path and of the spatial path (model/bisenet.py:31-60,109-116 via extractors.py:114).  The implicit-GEMM kernel spends 200 us per
+// 11 frames on it (K = 49 taps x 8 channels, every activation fetched ~12 times from L2, 64-channel tiles).  Here a persistent workgroup
+// keeps ALL weights in LDS (64 x 49 taps x 16 bytes) and per 8 x 32 output tile stages the 21 x 69 pixel input patch once; one MFMA K
+// step of 16 = two taps (lane half lh picks the tap), fragments are single ds_read_b128s: weights [co][tap] rows padded to an odd
+// multiple of 16 bytes, the patch split into even / odd column planes so that the stride-2 pixel walk of a wave is contiguous.
+// D[co][pixel] (A = weights): a lane owns one output pixel and 4 consecutive channels per accumulator group -> 8-byte stores.
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void conv16_stem_kernel(const Conv16Params p) {
+    constexpr int TH = 8, TW = 32, PH = 2 * TH + 5, PW = 2 * TW + 5, PLN = (PW + 1) / 2, PROW = 2 * PLN;     // 21 x 69 patch, 35-piece planes
+    constexpr int WROW = 51;                                  // weight row stride in 16-byte pieces (49 taps + pad: odd)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    u32x4 *Wl = reinterpret_cast<u32x4 *>(smem);                        // [64][WROW]
+    u32x4 *Pl = Wl + 64 * WROW;                                         // [PH][2][PLN]
+    f32x4 *SBl = reinterpret_cast<f32x4 *>(Pl + PH * PROW);              // [16] scale | [16] bias (global loads in the epilogue would be
+                                                                        // 16 exposed round trips per tile)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
+    for (int i = tid; i < 64 * 50; i += 256) {                // weights once per workgroup (tap 49 = the zero K padding)
+        const int co = i / 50, t = i - co * 50;
+        Wl[co * WROW + t] = *reinterpret_cast<const u32x4 *>(p.w + (size_t)co * p.Kpad + t * 8);
+    }
+    if (tid < 128) reinterpret_cast<float *>(SBl)[tid] = tid < 64 ? (p.scale ? p.scale[tid] : 1.0f) : (p.bias ? p.bias[tid - 64] : 0.0f);
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH, ntiles = p.N * tiles_x * tiles_y;
+    constexpr int NIT = (PH * PW + 255) / 256;                // patch items (pixel = one 16-byte piece) per thread
+    u32x4 pre[NIT];                                           // the NEXT tile's patch travels in registers under the MFMAs of the current one
+    auto patch_load = [&](int tile_) {
+        const int img_ = tile_ / (tiles_x * tiles_y), tr_ = tile_ - img_ * (tiles_x * tiles_y);
+        const int py0 = 2 * (tr_ / tiles_x) * TH - 3, px0 = 2 * (tr_ - (tr_ / tiles_x) * tiles_x) * TW - 3;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, row = i / PW, c = i - row * PW, gy = py0 + row, gx = px0 + c;
+            const bool ok = i < PH * PW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(((img_ * p.H + gy) * p.W + gx) * p.in_ld) * 2u : OOB, 0, 0);
+        }
+    };
+    auto patch_store = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int i = tid + it * 256, row = i / PW, c = i - row * PW;
+            if (i < PH * PW) Pl[row * PROW + (c & 1) * PLN + (c >> 1)] = pre[it];
+        }
+    };
+    if ((int)blockIdx.x < ntiles) patch_load(blockIdx.x);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int img = tile / (tiles_x * tiles_y), trem = tile - img * (tiles_x * tiles_y);
+        const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW;
+        __syncthreads();                                      // the previous tile's patch is no longer read (and the weights are in place)
+        patch_store();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) patch_load(tile + gridDim.x);
+        f32x16 acc[2][2];                                     // [co tile][pixel row of the wave]
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+#pragma unroll 5
+        for (int j = 0; j < 25; ++j) {
+            const int t = 2 * j + lh, tc = min(t, 48), r = (tc * 37) >> 8, sx = tc - 7 * r;      // tap (r, sx); t == 49 multiplies zero weights
+            u32x4 a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = Wl[(32 * i + li) * WROW + t];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) b[i] = Pl[(2 * (2 * wave + i) + r) * PROW + (sx & 1) * PLN + li + (sx >> 1)];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[i][k] = mfma16<BF>(a[i], b[k], acc[i][k]);
+        }
+        // epilogue: lane = pixel (column li of output row 2*wave + k), accumulator rows = channels (r&3) + 8*(r>>2) + 4*lh (+32 i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int oy = ty0 + 2 * wave + k, ox = tx0 + li;
+            if (oy >= p.Ho || ox >= p.Wo) continue;
+            uint16_t *dst = p.out + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.out_ld;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int co = 32 * i + 8 * q4 + 4 * lh;
+                    const f32x4 sc = SBl[co >> 2], bi = SBl[16 + (co >> 2)];
+                    uint16_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = arseg_f2h<BF>(act_apply(acc[i][k][4 * q4 + e] * sc[e] + bi[e], p.act, p.slope));
+                    *reinterpret_cast<u32x2 *>(dst + co) = u32x2{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16)};
+                }
+        }
+    }
+}
+
+template <bool BF>
+int launch_stem16(const Conv16Params &p, hipStream_t st) {
+    const size_t smem = (size_t)(64 * 51 + 21 * 70 + 32) * 16;
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_stem_kernel<BF>), smem)) return e;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    const long long ntiles = (long long)p.N * arseg_cdiv(p.Ho, 8) * arseg_cdiv(p.Wo, 32);
+    const int grid = (int)(ntiles < 2 * cus ? ntiles : 2 * cus);
+    hipLaunchKernelGGL((conv16_stem_kernel<BF>), dim3(grid), dim3(256), smem, st, p);
+    return arseg_launch_status();
+}
+
 // sums the split-K partials in slice order and applies the epilogue (scale, bias, residual, activation, one rounding to 16 bits);
 // 8 channels per thread (Cout % 8 == 0 with split-K)
 template <bool BF>
@@ -504,7 +610,7 @@ namespace {
 // split-K slices of a launch: explicit (desc.split_k >= 1) or, with 0, chosen so that a launch whose tiles do not fill the chip and
 // whose K loop is long gets ~2 workgroups per CU (the 16x32-map layers of BiSeNet-18: 176 tiles, K = 4608)
 int conv16_nsplit(const arseg_conv_desc *d, long long M, int Kpad, int co_t) {
-    if ((d->Cout & 7) || d->tile_cfg >= 5) return 1;          // (the patch-resident plans have no split-K)
+    if ((d->Cout & 7) || d->tile_cfg >= 5) return 1;          // (the patch-resident and stem plans have no split-K)
     const int kt64 = Kpad / 64;
     int ns = d->split_k;
     if (ns <= 0) {
@@ -557,7 +663,14 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     p.M = (int)M; p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
     // tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with K step 64
     const int cfg = d->tile_cfg;
-    if (cfg < 0 || cfg > 8) return ARSEG_EINVAL;
+    if (cfg < 0 || cfg > 9) return ARSEG_EINVAL;
+    if (cfg == 9) {          // stem kernel: 7x7 stride-2 pad-3, NHWC8 -> 64 channels, no residual
+        if (d->R != 7 || d->S != 7 || d->stride != 2 || d->pad != 3 || d->dil != 1 || d->Cin != 8 || d->Cout != 64 || residual || d->split_k > 1)
+            return ARSEG_EUNSUPPORTED;
+        p.patch_tw = 0; p.patch_l2tw = 0; p.tiles_m = 0; p.tiles_co = 1; p.tiles_px = 0; p.nsplit = 1; p.kt_per_split = 0; p.ws = nullptr;
+        hipStream_t st = arseg_stream(stream);
+        return dtype == ARSEG_DT_BF16 ? launch_stem16<true>(p, st) : launch_stem16<false>(p, st);
+    }
     if (cfg >= 5) {          // patch-resident 3x3 kernel: 5 / 6 = 128-pixel tiles with 64 / 128 output channels, 7 / 8 = 256-pixel tiles
         if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || (d->Cin & 63) || d->split_k > 1) return ARSEG_EUNSUPPORTED;
         const int bm = cfg >= 7 ? 256 : 128;

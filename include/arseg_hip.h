@@ -289,7 +289,8 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with
  *                       K step 64; 5..8 = patch-resident kernel for 3x3 stride-1 pad == dil convs with Cin % 64 == 0 (the input patch of a
  *                       128- (5, 6) / 256-pixel (7, 8) tile stays in LDS for all nine taps, 64 / 128 output channels; no split-K;
- *                       ARSEG_EUNSUPPORTED for other shapes); split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
+ *                       ARSEG_EUNSUPPORTED for other shapes); 9 = stem kernel (7x7 stride 2 pad 3, NHWC8 -> 64 channels, no residual: all weights
+ *                       resident in LDS, one staged input patch per 8x32 output tile); split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
  *                       layers of BiSeNet-18 --, >= 1 explicit; deterministic: fp32 partial sums in `workspace`
  *                       (arseg_conv2d16_workspace_bytes(desc) bytes, 0 without split-K), summed in slice order by a second kernel that
  *                       applies the epilogue; split-K needs Cout % 8 == 0, otherwise one slice.  batch unused)

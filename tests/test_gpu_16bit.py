@@ -49,6 +49,8 @@ CASES = [
     (1, 30, 40, 64, 72, 3, 1, 2, 2, "prelu", True, True, True),      # dilation, Cout not a multiple of the tile, bias
     (3, 37, 70, 128, 128, 3, 1, 1, 1, "relu", True, False, True),    # two 64-channel chunks, ragged 64-wide patch tiles, batch
     (1, 9, 150, 64, 192, 3, 1, 1, 1, "none", False, True, False),    # wide and flat, three 64-channel output tiles
+    (2, 64, 96, 3, 64, 7, 2, 3, 1, "relu", True, False, False),      # stem, whole tiles
+    (1, 18, 70, 3, 64, 7, 2, 3, 1, "prelu", False, True, False),     # stem, ragged in both directions
 ]
 
 
@@ -89,6 +91,9 @@ def test_conv2d16(dev, case, dtype):
     for cfg in (0, 1, 2, 3, 4):             # automatic choice, then every tile shape (64 / 128 channels x K step 32 / 64)
         got = ops.conv2d(xn.to(dev), pc, residual=rd, tile_cfg=cfg)
         assert got.dtype == dtype and got.shape == (N, y.shape[2], y.shape[3], Cout)
+        close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
+    if k == 7 and Cin == 3 and Cout == 64:                                # stem kernel
+        got = ops.conv2d(xn.to(dev), pc, tile_cfg=9)
         close16(got.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
     if k == 3 and stride == 1 and pad == dil and Cin % 64 == 0:          # patch-resident plans
         for cfg in (5, 6, 7, 8):
