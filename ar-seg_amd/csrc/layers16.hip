@@ -117,15 +117,25 @@ __global__ __launch_bounds__(256) void global_sum16_kernel(const uint16_t *__res
         }
     }
 }
-// step 2: out[n][c] = sum_s part[n][s][c] / HW  (fixed order: deterministic)
+// step 2: out[n][c] = sum_s part[n][s][c] / HW.  8 lanes per (n, c) take every 8th slice, their sums are combined in lane order
+// (a fixed order: deterministic); one thread per (n, c) walking all S slices was a chain of S dependent-latency loads (60 us at S = 1024).
 template <bool BF>
 __global__ __launch_bounds__(256) void global_mean_fin16_kernel(const float *__restrict__ part, uint16_t *__restrict__ out, int N, int C, int S, float inv) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int n = i / C, c = i - n * C;
+    __shared__ float red[8][32];
+    const int i = blockIdx.x * 32 + (threadIdx.x & 31), k = threadIdx.x >> 5;
     float t = 0.f;
-    for (int s = 0; s < S; ++s) t += part[((size_t)n * S + s) * C + c];
-    out[i] = arseg_f2h<BF>(t * inv);
+    if (i < N * C) {
+        const int n = i / C, c = i - n * C;
+        for (int s = k; s < S; s += 8) t += part[((size_t)n * S + s) * C + c];
+    }
+    red[k][threadIdx.x & 31] = t;
+    __syncthreads();
+    if (k == 0 && i < N * C) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a += red[j][threadIdx.x];
+        out[i] = arseg_f2h<BF>(a * inv);
+    }
 }
 
 // ------------------------------------------------------------------ resize (nearest / bilinear, align_corners on / off)
@@ -332,7 +342,7 @@ extern "C" int arseg_maxpool3x3s2_16_fwd(const void *in, void *out, int dtype, i
 
 static int mean16_slices(int N, int HW, int C) {
     long long blocks = (long long)arseg_cdiv(C, 256) * N;
-    int S = (int)(1024 / (blocks < 1 ? 1 : blocks));          // aim for ~1024 workgroups
+    int S = (int)(512 / (blocks < 1 ? 1 : blocks));           // aim for ~512 workgroups
     S = S < 1 ? 1 : S;
     const int maxS = (HW + 63) / 64;                           // at least 64 pixels per slice
     return S > maxS ? maxS : S;
@@ -351,7 +361,7 @@ extern "C" int arseg_global_mean16_fwd(const void *in, int in_ld, void *out, int
     if (!workspace || workspace_bytes < (size_t)N * S * C * sizeof(float)) return ARSEG_EWORKSPACE;
     const dim3 grid(arseg_cdiv(C, 256), N, S);
     float *part = (float *)workspace;
-    const int gf = arseg_cdiv((long long)N * C, 256);
+    const int gf = arseg_cdiv((long long)N * C, 32);
     hipStream_t st = arseg_stream(stream);
     const float inv = 1.0f / (float)(H * W);
     if (dtype == ARSEG_DT_BF16) {
