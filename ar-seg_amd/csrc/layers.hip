@@ -459,7 +459,7 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float *__re
 // columns j and j+1 (src = j + (r + 0.5) / S), so one thread takes such a run, loads its 4 taps once per class and evaluates the S
 // pixels from registers -- 4 loads per class and run instead of 4 S; the per-pixel kernel above issues 76 scattered loads per output
 // pixel at 19 classes and is bound by the texture path's instruction rate (77 us per 1024x2048 frame; this one: memory-side trivial).
-// Identical arithmetic (same taps, same weights from arseg_src_index, same blend expression) and argmax semantics.
+// Same taps and weights (arseg_src_index) and the same argmax semantics; the blend is regrouped (see below).
 template <int S>
 __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *__restrict__ logits, const int64_t *__restrict__ label,
                                                                   int32_t *__restrict__ pred, unsigned long long *__restrict__ hist,
@@ -493,24 +493,46 @@ __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *_
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const float *bk = b + (size_t)min(k0 + u, n_cls - 1) * cs;
-                t[u][0] = bk[o00]; t[u][1] = bk[o01]; t[u][2] = bk[o10]; t[u][3] = bk[o11];
+                if (x1 > x0) {          // the two taps of a row are neighbours: one 8-byte load (the kernel is bound by the number of load instructions)
+                    const float2 a01 = *reinterpret_cast<const float2 *>(bk + o00), a11 = *reinterpret_cast<const float2 *>(bk + o10);
+                    t[u][0] = a01.x; t[u][1] = a01.y; t[u][2] = a11.x; t[u][3] = a11.y;
+                } else {
+                    t[u][0] = bk[o00]; t[u][1] = bk[o01]; t[u][2] = bk[o10]; t[u][3] = bk[o11];
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (k0 + u >= n_cls) break;
+                // the bilinear blend is linear in lx along the run: v(r) = a + lx[r] * b -- one FMA per pixel and class (the expanded form,
+                // 6 operations, made this kernel VALU bound); same value up to fp32 rounding of the regrouped sum
+                const float a = (1.f - ly) * t[u][0] + ly * t[u][2];
+                const float b = (1.f - ly) * (t[u][1] - t[u][0]) + ly * (t[u][3] - t[u][2]);
 #pragma unroll
-                for (int r = 0; r < S; ++r) {
-                    const float v = (1.f - ly) * ((1.f - lx[r]) * t[u][0] + lx[r] * t[u][1]) + ly * ((1.f - lx[r]) * t[u][2] + lx[r] * t[u][3]);
-                    if (!bn[r] && (v > best[r] || v != v)) { best[r] = v; bi[r] = k0 + u; bn[r] = v != v; }
+                for (int r = 0; r < S; ++r) {          // branch free (the short-circuit form compiles to a divergent branch per pixel and class)
+                    const float v = fmaf(lx[r], b, a);
+                    const bool isn = v != v, take = !bn[r] & ((v > best[r]) | isn);
+                    best[r] = take ? v : best[r];
+                    bi[r] = take ? k0 + u : bi[r];
+                    bn[r] = bn[r] | (take & isn);
                 }
             }
         }
         const long long row = ((long long)n * H + oy) * W;
+        const bool whole = xs >= 0 && xs + S <= W;              // interior run: S consecutive labels, S/2 * 4 bytes aligned (W = S w, xs = S j + S/2)
+        if (pred && whole && S >= 4) {                           // vector stores (scalar ones: 4 bytes per lane at a 4 S byte stride)
+            if constexpr (S == 8) {
+                *reinterpret_cast<int4 *>(pred + row + xs) = int4{bi[0], bi[1], bi[2], bi[3]};
+                *reinterpret_cast<int4 *>(pred + row + xs + 4) = int4{bi[S > 4 ? 4 : 0], bi[S > 5 ? 5 : 0], bi[S > 6 ? 6 : 0], bi[S > 7 ? 7 : 0]};
+            } else {
+                *reinterpret_cast<int2 *>(pred + row + xs) = int2{bi[0], bi[1]};
+                *reinterpret_cast<int2 *>(pred + row + xs + 2) = int2{bi[S > 2 ? 2 : 0], bi[S > 3 ? 3 : 0]};
+            }
+        }
 #pragma unroll
         for (int r = 0; r < S; ++r) {
             const int ox = xs + r;
             if (ox < 0 || ox >= W) continue;
-            if (pred) pred[row + ox] = bi[r];
+            if (pred && !(whole && S >= 4)) pred[row + ox] = bi[r];
             if (hist && label) {
                 const long long lab = label[row + ox];
                 if (lab != ignore_label && lab >= 0 && lab < n_cls) atomicAdd(&lh[(int)lab * n_cls + bi[r]], 1u);
