@@ -440,7 +440,8 @@ __global__ __launch_bounds__(256) void argmax_confusion_kernel(const float *__re
             if (same) v = b[(size_t)oy * w + ox];
             else v = (1.f - ly) * ((1.f - lx) * b[(size_t)y0 * w + x0] + lx * b[(size_t)y0 * w + x1]) +
                      ly * ((1.f - lx) * b[(size_t)y1 * w + x0] + lx * b[(size_t)y1 * w + x1]);
-            if (!best_nan && (v > best || v != v)) { best = v; bi = k; best_nan = v != v; }
+            const bool isn = v != v, take = !best_nan & ((v > best) | isn);          // branch free
+            best = take ? v : best; bi = take ? k : bi; best_nan = best_nan | (take & isn);
         }
         if (pred) pred[pix] = bi;
         if (hist && label) {
