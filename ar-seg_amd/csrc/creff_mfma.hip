@@ -52,6 +52,19 @@ __device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
     hi = u32x2{h01, h23}; lo = u32x2{l01, l23};
 }
 // {hi, lo, hi}: dwords 0..3 are the operand {hi,lo}, dwords 2..5 the swapped operand {lo,hi} -- no register copies
+// reductions over the 4 DPP rows of a wave on the VALU (see creff_rr.hip): __shfl_xor is a ds_bpermute (LDS round trip + an address VGPR)
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ u32x6 pack6(const u32x2 hi, const u32x2 lo) { return u32x6{hi.x, hi.y, lo.x, lo.y, hi.x, hi.y}; }
 __device__ __forceinline__ h16x8 op_a(const u32x6 v) { return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 0, 1, 2, 3)); }
 __device__ __forceinline__ h16x8 op_b(const u32x6 v) { return __builtin_bit_cast(h16x8, __builtin_shufflevector(v, v, 2, 3, 4, 5)); }
@@ -104,7 +117,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     f32x4 *Tb = Wfs + 2 * G * NBA * 16;         // bilinear tables: [LH] rows then [LWD] columns of the lr_up tile
     u32x4 *Kl = reinterpret_cast<u32x4 *>(Tb + LH + LWD);   // key / value records [G][RH*RW]: {4 hi halves | 4 lo halves}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, tid_ = tid, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 15, g = lane >> 4, qy = q >> 3, qx = q & 7;
     const int pc = wave & 1, pr = wave >> 1;
     // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (private L2s); give each XCD a
@@ -161,15 +174,6 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     constexpr int K_TOT = G * RH * RWC, K_NI = (K_TOT + NT - 1) / NT;
     constexpr int L_TOT = G * LH * LWD, L_NI = (L_TOT + NT - 1) / NT;
     constexpr unsigned BAD = 0x80000000u;             // beyond num_records even after the chunk offset is added
-    unsigned hoff[H_NI];                               // byte offset inside the image's first chunk, or BAD
-#pragma unroll
-    for (int it = 0; it < H_NI; ++it) {
-        const int i = tid + it * NT;                   // = index in the Hs image (the LDS-DMA destination is lane linear)
-        const int gg = i / HPL, px = i - gg * HPL, r = px / HWD, c = px - r * HWD;
-        const int gy = ty0 - 4 + r, gx = tx0 - 4 + c;
-        const bool ok = i < H_TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
-        hoff[it] = ok ? (unsigned)((((gg >> 1) * p.Hp + gy) * p.Wp + gx) * 8 + (gg & 1) * 4) * 4u : BAD;
-    }
     int kh[K_NI], kk[K_NI], kg[K_NI];                  // Hs read index, Kl write index, channel group
     bool kin[K_NI];
 #pragma unroll
@@ -197,13 +201,26 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     const int lw_tot = G * ly_n * lx_n;
     f32x4 pf_w;
     auto issue_hr = [&](int k, int buf) {
+        // the offsets are decoded again per chunk from an opaque thread id: kept in registers across the chunk loops they were spilled,
+        // and every reload from scratch waited (vmcnt(0)) for the DMA issued just before it -- three serialised round trips per chunk
+        int t_ = tid; asm volatile("" : "+v"(t_));
 #pragma unroll
         for (int it = 0; it < H_NI; ++it)
-            if (it * NT + wave_u * 64 < H_TOT)
-                dma16_buf(h_rsrc, hoff[it] + k * h_chunk, lds_addr(Hs + (HBUF == 2 ? buf : 0) * G * HPL + it * NT + wave_u * 64));
+            if (it * NT + wave_u * 64 < H_TOT) {
+                const int i = t_ + it * NT;
+                const int gg = i / HPL, px = i - gg * HPL, r = px / HWD, c = px - r * HWD;
+                const int gy = ty0 - 4 + r, gx = tx0 - 4 + c;
+                const bool ok = i < H_TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
+                const unsigned ho = ok ? (unsigned)((((gg >> 1) * p.Hp + gy) * p.Wp + gx) * 8 + (gg & 1) * 4) * 4u : BAD;
+                dma16_buf(h_rsrc, ho + k * h_chunk, lds_addr(Hs + (HBUF == 2 ? buf : 0) * G * HPL + it * NT + wave_u * 64));
+            }
     };
     auto issue = [&](int k, int buf, bool head) {
         if (HBUF == 2) issue_hr(k, buf);           // double buffered: nobody reads the other half now
+        // the source addresses are recomputed per chunk from an opaque copy of the thread id: as loop invariants hipcc keeps three 64-bit
+        // per-lane pointers live across both chunk loops, spills them and reloads them from scratch in every iteration (a vmcnt wait
+        // that also waits for the LDS-DMA just issued)
+        int tid = tid_; asm volatile("" : "+v"(tid));
         if (wave_u * 64 < lw_tot) {
             const int i = min(tid, lw_tot - 1);          // surplus lanes of the last wave repeat the last item (stay inside Lw)
             const int npx = ly_n * lx_n, gg = i / npx, px = i - gg * npx, r = px / lx_n, c = px - r * lx_n;
@@ -310,7 +327,8 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     // ------------------------------------------------------------------ softmax over the 49 taps (padding taps included)
     // S[b][i] = score(query q, key row b, key column 4g+i); tap (b - qy, 4g+i - qx) is real iff both are in [0,6]
     float inv;
-    u32x6 P6[8];
+    u32x4 P4[8];          // {hi | lo}: the swapped operand {lo | hi} is rebuilt per use (4 moves) -- as 6-register {hi, lo, hi} aliases the 8
+                          // blocks cost 48 VGPRs and the kernel spilled into its chunk loops (scratch reloads wait on vmcnt with the DMA)
     {
         bool colok[4];
 #pragma unroll
@@ -325,8 +343,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
                 m = fmaxf(m, S[b][i]);
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
+        m = rows_max(m);
         const float ml = m * LOG2E;
         float z = 0.f;
 #pragma unroll
@@ -338,10 +355,9 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
             }
             u32x2 hi, lo;
             split4(S[b], hi, lo);
-            P6[b] = pack6(hi, lo);
+            P4[b] = u32x4{hi.x, hi.y, lo.x, lo.y};
         }
-        z += __shfl_xor(z, 16);
-        z += __shfl_xor(z, 32);
+        z = rows_sum(z);
         inv = 1.0f / z;                            // applied to the weighted sum instead of the 128 weights
     }
 
@@ -350,6 +366,9 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool inq = gyq < p.Hp && gxq < p.Wp;
     const u32x4 p_rsrc = make_rsrc(p.p_out, p.p_bytes), l_rsrc = make_rsrc(p.logits, p.l_bytes);
+    // p (C8 layout) offset of this lane's query in chunk k: ((((n C/8 + 2k + g/2) Hp + gyq) Wp + gxq) 8 + (g&1) 4) floats
+    const unsigned p_off0 = (((((unsigned)n * (unsigned)(p.C >> 3) + (unsigned)(g >> 1)) * p.Hp + gyq) * p.Wp + gxq) * 8u + (g & 1) * 4u) * 4u;
+    const unsigned p_kstep = 2u * (unsigned)p.Hp * (unsigned)p.Wp * 32u;
 
     // ------------------------------------------------------------------ pass 2: weighted values, residual, head
     for (int k = 0; k < CB; ++k) {
@@ -365,11 +384,11 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const h16x8 a = pack8(lds_tr16(va + b * RW * 16), lds_tr16(va + b * RW * 16 + 8));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_a(P6[b]), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_b(P6[b]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h16x8, P4[b]), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, __builtin_bit_cast(h16x8, u32x4{P4[b].z, P4[b].w, P4[b].x, P4[b].y}), acc, 0, 0, 0);
         }
         const f32x4 o = lrc + acc * inv;              // p[query][16k + 4g .. +3]
-        const unsigned off = (unsigned)(((((size_t)n * (p.C >> 3) + 2 * k + (g >> 1)) * p.Hp + gyq) * p.Wp + gxq) * 8 + (g & 1) * 4) * 4u;
+        const unsigned off = p_off0 + (unsigned)k * p_kstep;       // 32-bit: the 64-bit form kept three hoisted partial products in spilled registers
         store16_buf(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? off : OOB);
         if (NB > 0) {
             u32x2 oh, ol;
@@ -397,15 +416,13 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
                 m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
             }
         if (p.log_softmax) {
-            m = fmaxf(m, __shfl_xor(m, 16));
-            m = fmaxf(m, __shfl_xor(m, 32));
+            m = rows_max(m);
             float z = 0.f;
 #pragma unroll
             for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? expf(lg[nb][i] - m) : 0.f;
-            z += __shfl_xor(z, 16);
-            z += __shfl_xor(z, 32);
+            z = rows_sum(z);
             const float lse = m + logf(z);
 #pragma unroll
             for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
