@@ -33,6 +33,7 @@
 //                     power of two so that lo stays a normal fp16) once at pack time; activations stay fp32 in HBM and
 //                     are split on their way into LDS, whose row layout becomes [32 hi halves | 32 lo halves | pad].
 #include "arseg_common.h"
+#include <type_traits>
 #include <cmath>
 #include <cstring>
 
@@ -58,6 +59,7 @@ struct ConvParams {
     int inv_S;                       // 65536/S + 1: r = (rs*inv_S) >> 16 without a division
     int up2;                         // patch kernel: `in` is the low-resolution tensor [N, H/2, W/2, in_ld], convolved after a x2 bilinear upsample
     unsigned in_bytes, w_bytes;      // extents for the buffer descriptors
+    unsigned out_bytes, res_bytes;   // extent of one problem's output / residual if below 2 GiB (branch-free epilogue through buffer stores), else 0
     long long in_bs, w_bs, out_bs;   // batched GEMM mode (blockIdx.y = batch index): element strides between problems
 };
 
@@ -75,6 +77,27 @@ __device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo)
     unsigned h01, h23, l01, l23;
     arseg_split_f16(v, h01, h23, l01, l23);
     hi = uint2{h01, h23}; lo = uint2{l01, l23};
+}
+
+// Branch-free epilogue of one accumulator element: scale, bias, residual, activation, store.  The bounds tests become out-of-range
+// buffer offsets (loads return 0, stores are dropped), the activation is arithmetic on two uniform parameters -- the per-element
+// `continue` / `if (res)` / switch form compiled to ~3 branches and a 64-bit multiply per element (a fifth of a short-K tile's time).
+struct EpiAct { float slope, lo; bool sigmoid; };
+__device__ __forceinline__ EpiAct epi_act(int act, float slope) {
+    EpiAct a;
+    a.slope = act == ARSEG_ACT_PRELU ? slope : 1.0f;               // v >= 0 ? v : v * slope   (NONE / RELU: slope 1)
+    a.lo = act == ARSEG_ACT_RELU ? 0.0f : -INFINITY;                // then max(v, lo)
+    a.sigmoid = act == ARSEG_ACT_SIGMOID;
+    return a;
+}
+template <bool RES>
+__device__ __forceinline__ void epi_store(float v, float sc, float bi, const EpiAct a, const __amdgpu_buffer_rsrc_t o_rsrc,
+                                          const __amdgpu_buffer_rsrc_t r_rsrc, unsigned o_off, unsigned r_off) {
+    v = v * sc + bi;
+    if constexpr (RES) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, r_off, 0, 0));
+    if (a.sigmoid) v = 1.0f / (1.0f + __expf(-v));                  // (uniform)
+    else v = fmaxf(v >= 0.0f ? v : v * a.slope, a.lo);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), o_rsrc, o_off, 0, 0);
 }
 
 template <int BM, int BN, int BK, int NBUF, int MATH, int NWM = 2, int NWN = 2>      // NWM x NWN waves, wave tile BM/NWM x BN/NWN
@@ -322,6 +345,32 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
     if (DUAL) acc[0][0] += acc2[0];
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.nsplit == 1 && p.out_bytes) {
+        constexpr unsigned OOBS = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(gout, 0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : gout), 0, (int)p.res_bytes, 0x00020000);
+        const EpiAct ea = epi_act(p.act, p.slope);
+        auto run = [&](auto res_tag) {
+            constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = n0 + wn * (BN / NWN) + tn * 32 + li, nc = min(n, p.Cout - 1);
+                    const float sc = p.scale ? p.scale[nc] : 1.0f, bi = p.bias ? p.bias[nc] : 0.0f;
+                    const int mb = m0 + wm * (BM / NWM) + tm * 32 + 4 * lh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        const bool ok = n < p.Cout && m < p.M;
+                        epi_store<RES>(acc[tm][tn][r], sc, bi, ea, o_rsrc, r_rsrc, ok ? ((unsigned)m * (unsigned)p.out_ld + (unsigned)n) * 4u : OOBS,
+                                       ok ? ((unsigned)m * (unsigned)p.res_ld + (unsigned)n) * 4u : OOBS);
+                    }
+                }
+        };
+        if (p.res) run(std::true_type{}); else run(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -575,6 +624,33 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.out_bytes) {
+        constexpr unsigned OOBS = 0x80000000u;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)p.out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.res ? p.res : p.out), 0, (int)p.res_bytes, 0x00020000);
+        const EpiAct ea = epi_act(p.act, p.slope);
+        auto run = [&](auto res_tag) {
+            constexpr bool RES = decltype(res_tag)::value;
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) {
+                    const int n = n0 + wn * (BN / 2) + tn * 32 + li, nc = min(n, p.Cout - 1);
+                    const float sc = p.scale ? p.scale[nc] : 1.0f, bi = p.bias ? p.bias[nc] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ml = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int oy = ty0 + (ml >> log2TW), ox = tx0 + (ml & (TW - 1));
+                        const bool ok = n < p.Cout && oy < p.Ho && ox < p.Wo;
+                        const unsigned m = ((unsigned)img * (unsigned)p.Ho + (unsigned)oy) * (unsigned)p.Wo + (unsigned)ox;
+                        epi_store<RES>(acc[tm][tn][r], sc, bi, ea, o_rsrc, r_rsrc, ok ? (m * (unsigned)p.out_ld + (unsigned)n) * 4u : OOBS,
+                                       ok ? (m * (unsigned)p.res_ld + (unsigned)n) * 4u : OOBS);
+                    }
+                }
+        };
+        if (p.res) run(std::true_type{}); else run(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
@@ -792,6 +868,12 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     p.inv_S = 65536 / d->S + 1;
     p.in_bytes = (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);
     p.w_bytes = (unsigned)((long long)d->Cout * pl.Kpad * 4);
+    {
+        const long long ob = (((long long)pl.M - 1) * d->out_ld + d->Cout) * 4, rb = (((long long)pl.M - 1) * d->res_ld + d->Cout) * 4;
+        const bool fits = ob < (1ll << 31) && (!residual || rb < (1ll << 31));
+        p.out_bytes = fits ? (unsigned)ob : 0u;
+        p.res_bytes = fits ? (residual ? (unsigned)rb : (unsigned)ob) : 0u;
+    }
     p.Ho = pl.Ho; p.Wo = pl.Wo; p.Cout = d->Cout; p.out_ld = d->out_ld; p.res_ld = d->res_ld;
     p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.K = pl.K; p.Kpad = pl.Kpad; p.M = pl.M;
