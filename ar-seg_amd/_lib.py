@@ -42,6 +42,8 @@ PROTOTYPES = {
     "arseg_status_string": (c_char_p, [c_int]),
     "arseg_local_similar_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_local_weighting_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_local_similar_nhwc_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_local_weighting_nhwc_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_warp_fwd": (c_int, [_P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_mv_resize_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_flow_resize_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
@@ -93,6 +95,13 @@ PROTOTYPES = {
     "arseg_nhwc_to_nchw_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _STREAM]),
     "arseg_argmax_confusion_fwd": (c_int, [_P, _P, _P, _P] + [c_int] * 8 + [_STREAM]),
 }
+
+# the SURVEY.md section 8(b) names: aliases with the prototypes of their targets
+for _alias, _target in (("arseg_creff_fused_fwd", "arseg_creff_warp_fwd"), ("arseg_conv2d_bn_act_fwd", "arseg_conv2d_fwd"),
+                        ("arseg_pack_weights", "arseg_pack_conv_weight_host"), ("arseg_maxpool3x3s2", "arseg_maxpool3x3s2_fwd"),
+                        ("arseg_adaptive_avgpool", "arseg_adaptive_avgpool_fwd"), ("arseg_global_reduce", "arseg_global_reduce_fwd"),
+                        ("arseg_resize", "arseg_resize_fwd"), ("arseg_scale_add", "arseg_scale_add_fwd")):
+    PROTOTYPES[_alias] = PROTOTYPES[_target]
 
 _lib = None
 

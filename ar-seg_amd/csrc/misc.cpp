@@ -62,3 +62,37 @@ extern "C" int arseg_pack_conv_weight16_host(const float *w, int Cout, int Cin, 
     }
     return ARSEG_OK;
 }
+
+// ---- the symbol names of SURVEY.md section 8(b), as aliases (include/arseg_hip.h)
+extern "C" int arseg_creff_fused_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr, const float *wq,
+                                     const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float *p_out,
+                                     int p_layout, const float *wf, const float *bf, int n_cls, float *logits, int log_softmax, int N, int C,
+                                     int Hp, int Wp, int hp, int wp, int kH, int kW, arseg_stream_t stream) {
+    return arseg_creff_warp_fwd(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits, log_softmax, N, C, Hp,
+                                Wp, hp, wp, kH, kW, stream);
+}
+extern "C" int arseg_conv2d_bn_act_fwd(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale, const float *bias,
+                                       const float *residual, float *out, void *workspace, size_t workspace_bytes, arseg_stream_t stream) {
+    return arseg_conv2d_fwd(d, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);
+}
+extern "C" int arseg_pack_weights(const float *w, int Cout, int Cin, int R, int S, int Cin_pad, float *out_host) {
+    return arseg_pack_conv_weight_host(w, Cout, Cin, R, S, Cin_pad, out_host);
+}
+extern "C" int arseg_maxpool3x3s2(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream) {
+    return arseg_maxpool3x3s2_fwd(in, out, N, H, W, C, stream);
+}
+extern "C" int arseg_adaptive_avgpool(const float *in, int in_ld, float *out, int out_ld, long long out_n_stride, int N, int H, int W, int C,
+                                      int oh, int ow, arseg_stream_t stream) {
+    return arseg_adaptive_avgpool_fwd(in, in_ld, out, out_ld, out_n_stride, N, H, W, C, oh, ow, stream);
+}
+extern "C" int arseg_global_reduce(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op, arseg_stream_t stream) {
+    return arseg_global_reduce_fwd(in, in_ld, out, N, H, W, C, op, stream);
+}
+extern "C" int arseg_resize(const float *in, float *out, int N, int C, int Hin, int Win, int Hout, int Wout, int mode, int align_corners,
+                            int layout, int in_ld, int out_ld, arseg_stream_t stream) {
+    return arseg_resize_fwd(in, out, N, C, Hin, Win, Hout, Wout, mode, align_corners, layout, in_ld, out_ld, stream);
+}
+extern "C" int arseg_scale_add(const float *x, const float *scale, const float *add_full, const float *add_vec, float *out, int N, int HW,
+                               int C, arseg_stream_t stream) {
+    return arseg_scale_add_fwd(x, scale, add_full, add_vec, out, N, HW, C, stream);
+}

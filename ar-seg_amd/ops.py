@@ -210,19 +210,33 @@ def from_c8(x: torch.Tensor, layout: int) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # localAttention pair
 # ----------------------------------------------------------------------------------------------
+def _is_cl(t: torch.Tensor) -> bool:
+    return t.dim() == 4 and t.shape[1] > 1 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
 def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
+    """localAttention.similar_forward; channels_last inputs go to the NHWC variant without a layout change."""
     _need_gpu(q, k)
-    q, k = q.contiguous(), k.contiguous()
     N, C, H, W = q.shape
     out = torch.empty((N, H, W, kH * kW), dtype=torch.float32, device=q.device)
+    if _is_cl(q) and _is_cl(k):
+        _launch("local_similar", _lib.load().arseg_local_similar_nhwc_fwd, _ptr(q), _ptr(k), C, _ptr(out), N, C, H, W, kH, kW, _stream())
+        return out
+    q, k = q.contiguous(), k.contiguous()
     _launch("local_similar", _lib.load().arseg_local_similar_fwd, _ptr(q), _ptr(k), _ptr(out), N, C, H, W, kH, kW, _stream())
     return out
 
 
 def local_weighting(v: torch.Tensor, w: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
+    """localAttention.weighting_forward; a channels_last ``v`` gives a channels_last result through the NHWC variant."""
     _need_gpu(v, w)
-    v, w = v.contiguous(), w.contiguous()
+    w = w.contiguous()
     N, C, H, W = v.shape
+    if _is_cl(v):
+        out = torch.empty_like(v, memory_format=torch.channels_last)
+        _launch("local_weighting", _lib.load().arseg_local_weighting_nhwc_fwd, _ptr(v), _ptr(w), C, _ptr(out), N, C, H, W, kH, kW, _stream())
+        return out
+    v = v.contiguous()
     out = torch.empty_like(v)
     _launch("local_weighting", _lib.load().arseg_local_weighting_fwd, _ptr(v), _ptr(w), _ptr(out), N, C, H, W, kH, kW, _stream())
     return out

@@ -58,6 +58,12 @@ int arseg_local_similar_fwd(const float *q, const float *k, float *s, int N, int
                             arseg_stream_t stream);
 int arseg_local_weighting_fwd(const float *v, const float *w, float *o, int N, int C, int H, int W, int kH, int kW,
                               arseg_stream_t stream);
+/* The same pair on NHWC (torch.channels_last) features: element (n,c,y,x) at ((n*H + y)*W + x)*ld + c, ld >= C shared by the two inputs
+ * (similar) / by v and o (weighting); s, w keep [N,H,W,kH*kW].  No layout change between the NHWC backbone tensors and the op. */
+int arseg_local_similar_nhwc_fwd(const float *q, const float *k, int ld, float *s, int N, int C, int H, int W, int kH, int kW,
+                                 arseg_stream_t stream);
+int arseg_local_weighting_nhwc_fwd(const float *v, const float *w, int ld, float *o, int N, int C, int H, int W, int kH, int kW,
+                                   arseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * warpFeature(feature, flow)                                            evaluation.py:61-87
@@ -336,6 +342,30 @@ int arseg_warp_mvq16_fwd(const void *feature, int dtype, const int16_t *mv_q, fl
  * ------------------------------------------------------------------------------------------- */
 int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_t *pred, int64_t *hist, int N,
                                int n_cls, int h, int w, int H, int W, int ignore_label, int align_corners, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The symbol names SURVEY.md section 8(b) lists for this boundary, as aliases of the entry points above (identical arguments):
+ *   arseg_creff_fused_fwd     = arseg_creff_warp_fwd      (warp + CReFF + final 1x1 in one launch)
+ *   arseg_conv2d_bn_act_fwd   = arseg_conv2d_fwd          arseg_pack_weights      = arseg_pack_conv_weight_host
+ *   arseg_maxpool3x3s2        = arseg_maxpool3x3s2_fwd    arseg_adaptive_avgpool  = arseg_adaptive_avgpool_fwd
+ *   arseg_global_reduce       = arseg_global_reduce_fwd   arseg_resize            = arseg_resize_fwd
+ *   arseg_scale_add           = arseg_scale_add_fwd
+ * ------------------------------------------------------------------------------------------- */
+int arseg_creff_fused_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr, const float *wq,
+                          const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float *p_out, int p_layout,
+                          const float *wf, const float *bf, int n_cls, float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp,
+                          int wp, int kH, int kW, arseg_stream_t stream);
+int arseg_conv2d_bn_act_fwd(const arseg_conv_desc *d, const float *in, const float *w_packed, const float *scale, const float *bias,
+                            const float *residual, float *out, void *workspace, size_t workspace_bytes, arseg_stream_t stream);
+int arseg_pack_weights(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, float *out_host);
+int arseg_maxpool3x3s2(const float *in, float *out, int N, int H, int W, int C, arseg_stream_t stream);
+int arseg_adaptive_avgpool(const float *in, int in_ld, float *out, int out_ld, long long out_n_stride, int N, int H, int W, int C, int oh,
+                           int ow, arseg_stream_t stream);
+int arseg_global_reduce(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op, arseg_stream_t stream);
+int arseg_resize(const float *in, float *out, int N, int C, int Hin, int Win, int Hout, int Wout, int mode, int align_corners, int layout,
+                 int in_ld, int out_ld, arseg_stream_t stream);
+int arseg_scale_add(const float *x, const float *scale, const float *add_full, const float *add_vec, float *out, int N, int HW, int C,
+                    arseg_stream_t stream);
 
 #ifdef __cplusplus
 }

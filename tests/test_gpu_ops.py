@@ -39,6 +39,12 @@ def test_local_pair(dev, N, C, H, W, kH, kW):
     assert maxdiff(o, cpu_ref.local_weighting(k, w, kH, kW)) <= 1e-5
     assert maxdiff(s, c_ref.local_similar(q.numpy(), k.numpy(), kH, kW)) <= 1e-4
     assert maxdiff(o, c_ref.local_weighting(k.numpy(), w.numpy(), kH, kW)) <= 1e-5
+    # NHWC (channels_last) variants: same results, no layout change
+    qc, kc = q.to(dev).contiguous(memory_format=torch.channels_last), k.to(dev).contiguous(memory_format=torch.channels_last)
+    s2 = ops.local_similar(qc, kc, kH, kW).cpu()
+    o2 = ops.local_weighting(kc, w.to(dev), kH, kW)
+    assert maxdiff(s2, s) <= 1e-5 and maxdiff(o2.cpu(), o) <= 1e-6
+    assert C == 1 or o2.is_contiguous(memory_format=torch.channels_last)
 
 
 def test_local_pair_golden_and_shim(dev, golden):
