@@ -67,15 +67,19 @@ class GopRunner:
             raise ValueError(f"n_gops ({n_gops}) must be a multiple of the world size ({self.world})")
         self.plan = frame_plan(n_gops, gop, self.world)[self.rank]
         self.my_gops = [g for g in range(n_gops) if keyframe_owner(g, self.world) == self.rank]
-        self._gather_buf: Optional[torch.Tensor] = None          # reused across steps (1 GB at world 8 for the PSPNet feature)
-        self._side_stream = None
+        # gather buffer (1 GB at world 8 for the PSPNet feature) and side stream, one pair PER LAUNCH STREAM: steps rotated over several
+        # streams run concurrently, and a single buffer would be overwritten by the next step's collective while this step's warp +
+        # CReFF still read it (the side stream's wait on ITS launch stream orders a buffer's reuse behind its previous consumer)
+        self._gather_bufs: Dict[int, torch.Tensor] = {}
+        self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     # ------------------------------------------------------------------ the exchange step
     def _buffer(self, stacked: torch.Tensor) -> torch.Tensor:
         shape = (self.world * stacked.shape[0],) + tuple(stacked.shape[1:])
-        b = self._gather_buf
+        key = self._lane if stacked.is_cuda else 0
+        b = self._gather_bufs.get(key)
         if b is None or tuple(b.shape) != shape or b.dtype != stacked.dtype or b.device != stacked.device:
-            b = self._gather_buf = torch.empty(shape, dtype=stacked.dtype, device=stacked.device)
+            b = self._gather_bufs[key] = torch.empty(shape, dtype=stacked.dtype, device=stacked.device)
         return b
 
     def _index(self, gathered: torch.Tensor, per_rank: int) -> List[torch.Tensor]:
@@ -85,6 +89,8 @@ class GopRunner:
             for i, g in enumerate(owned):
                 refs[g] = gathered[r, i]
         return refs
+
+    _lane = 0          # launch stream of the step being enqueued (key of its gather buffer / side stream)
 
     def exchange(self, local_refs: Sequence[torch.Tensor], like: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         """Keyframe features for every GOP, indexed by gop.  Batched plan: one all-gather; single-GOP plan: one broadcast from
@@ -109,6 +115,8 @@ class GopRunner:
     # ------------------------------------------------------------------ schedules
     def run(self, keyframes, frames, mvs, like: Optional[torch.Tensor] = None):
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
+        if local_refs and local_refs[0].is_cuda:
+            self._lane = torch.cuda.current_stream().cuda_stream
         refs = self.exchange(local_refs, like)
         return {(g, d): self.nonkey_fn(refs[g], frames[(g, d)], mvs[(g, d)]) for (g, d) in self.plan}
 
@@ -116,6 +124,8 @@ class GopRunner:
         """Same schedule with this rank's non-keyframes processed as ONE batch: ``frames_stacked`` / ``mvs_stacked`` hold
         the frames of ``self.plan`` in plan order along dim 0; ``batch_fn(refs_per_frame, frames, mvs)`` -> outputs."""
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
+        if frames_stacked.is_cuda:
+            self._lane = torch.cuda.current_stream().cuda_stream
         refs = self.exchange(local_refs, like)
         return batch_fn([refs[g] for (g, _) in self.plan], frames_stacked, mvs_stacked)
 
@@ -126,14 +136,16 @@ class GopRunner:
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
         on_gpu = frames_stacked.is_cuda and self.world > 1
         if on_gpu:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=frames_stacked.device)
             main = torch.cuda.current_stream()
-            self._side_stream.wait_stream(main)                     # the HR forward has produced local_refs
-            with torch.cuda.stream(self._side_stream):
+            self._lane = main.cuda_stream
+            side = self._side_streams.get(self._lane)
+            if side is None:
+                side = self._side_streams[self._lane] = torch.cuda.Stream(device=frames_stacked.device)
+            side.wait_stream(main)                                  # the HR forward has produced local_refs; the lane's previous step is done with its buffer
+            with torch.cuda.stream(side):
                 refs = self.exchange(local_refs, like)
             feat = phase1_fn(frames_stacked)                        # overlaps the collective
-            main.wait_stream(self._side_stream)
+            main.wait_stream(side)
             for r in refs:
                 r.record_stream(main)
         else:
