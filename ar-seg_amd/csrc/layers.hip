@@ -288,6 +288,79 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ p, 
     }
 }
 
+// The same head on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulation): D[class][pixel] = W . P^T per
+// 32-pixel tile of a wave.  The pixel tile is staged through LDS with coalesced 16-byte loads (the one-thread-per-pixel kernel above walks
+// 256-byte rows with a lane stride of 256 bytes and re-reads the weights from LDS per pixel: 108 us for the 512x1024x64 keyframe feature
+// against ~35 us of memory time).  K order: lane half lh covers channels [lh*C/2, (lh+1)*C/2) so a lane's operands are contiguous (one
+// ds_read_b128 per 4 MFMAs and operand).  A lane owns one pixel and 16 of the 32 class rows; LogSoftmax needs one cross-half exchange.
+__global__ __launch_bounds__(256) void head_mfma_kernel(const float *__restrict__ p, int p_ld, const float *__restrict__ wf,
+                                                        const float *__restrict__ bf, float *__restrict__ logits, int N, int HW, int C,
+                                                        int n_cls, int log_softmax) {
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int PS = C + 4;                                   // row stride (floats): 16-byte aligned, rows 4 slots apart (conflict-free b128 reads)
+    float *Wl = hsm;                                        // [32][PS] (rows >= n_cls zero)
+    float *Bl = Wl + 32 * PS;                               // [32] bias
+    float *Pl = Bl + 32 + (threadIdx.x >> 6) * 32 * PS;     // this wave's pixel tile [32][PS]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, c4n = C >> 2;
+    for (int i = tid; i < 32 * c4n; i += 256) {
+        const int r = i / c4n, c = (i - r * c4n) * 4;
+        *reinterpret_cast<f32x4 *>(Wl + r * PS + c) = r < n_cls ? *reinterpret_cast<const f32x4 *>(wf + (size_t)r * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 32) Bl[tid] = tid < n_cls ? bf[tid] : 0.f;
+    __syncthreads();
+    const long long total = (long long)N * HW, ntile = (total + 31) / 32;
+    const int npc = (32 * c4n + 63) / 64;                   // 16-byte pieces of a tile per lane (8 at C = 64)
+    for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long px0 = tile * 32;
+        for (int j = 0; j < npc; ++j) {                     // stage the tile: consecutive lanes, consecutive 16-byte pieces
+            const int i = lane + 64 * j, r = i / c4n, c = (i - r * c4n) * 4;
+            if (i < 32 * c4n) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (px0 + r < total) v = *reinterpret_cast<const f32x4 *>(p + (size_t)(px0 + r) * p_ld + c);
+                *reinterpret_cast<f32x4 *>(Pl + r * PS + c) = v;
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const float *wa = Wl + li * PS + lh * (C >> 1), *pb = Pl + li * PS + lh * (C >> 1);
+        for (int k = 0; k < (C >> 1); k += 4) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(wa + k), b = *reinterpret_cast<const f32x4 *>(pb + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+        }
+        // lane = pixel li; acc[r] = class (r&3) + 8*(r>>2) + 4*lh
+        float m = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cls = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            acc[r] += Bl[cls];
+            m = fmaxf(m, cls < n_cls ? acc[r] : -INFINITY);
+        }
+        if (log_softmax) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            float z = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z += (r & 3) + 8 * (r >> 2) + 4 * lh < n_cls ? expf(acc[r] - m) : 0.f;
+            auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+            const float lse = m + logf(__uint_as_float(sz[0]) + __uint_as_float(sz[1]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] -= lse;
+        }
+        const long long pix = px0 + li;
+        if (pix < total) {
+            const int n = (int)(pix / HW);
+            const long long hw = pix - (long long)n * HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cls = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cls < n_cls) logits[((size_t)n * n_cls + cls) * HW + hw] = acc[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ frame ingest: NCHW RGB -> NHWC4 (+ downscale)
 __global__ __launch_bounds__(256) void frame_to_nhwc4_kernel(const float *__restrict__ img, float *__restrict__ out, int N, int H,
                                                              int W, int h, int w) {
@@ -646,9 +719,18 @@ extern "C" int arseg_head_fwd(const float *p, int p_ld, const float *wf, const f
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(HW); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(n_cls);
     if ((C & 3) || (p_ld & 3) || p_ld < C) return ARSEG_EINVAL;
     if (n_cls > 32 || (size_t)n_cls * C * sizeof(float) > 60 * 1024) return ARSEG_EUNSUPPORTED;
+    hipStream_t st = arseg_stream(stream);
+    if (!(C & 7) && C <= 128 && ARSEG_ALIGNED16(p) && ARSEG_ALIGNED16(wf)) {           // fp32 matrix-core kernel: 4 waves x 32-pixel tiles per workgroup
+        const size_t sm = (size_t)(5 * 32 * (C + 4) + 32) * sizeof(float);
+        static ArsegSmemAttr attr;
+        if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(head_mfma_kernel), sm)) return e;
+        const long long ntile = ((long long)N * HW + 31) / 32;
+        long long gb = (ntile + 3) / 4;
+        hipLaunchKernelGGL(head_mfma_kernel, dim3((unsigned)(gb > 2048 ? 2048 : gb)), dim3(256), sm, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        return arseg_launch_status();
+    }
     const size_t smem = (size_t)n_cls * C * sizeof(float);
     const int g = grid_for((long long)N * HW, 2048);
-    hipStream_t st = arseg_stream(stream);
     if (n_cls <= 12) hipLaunchKernelGGL(head_kernel<12>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
     else if (n_cls <= 19) hipLaunchKernelGGL(head_kernel<19>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
     else hipLaunchKernelGGL(head_kernel<32>, dim3(g), dim3(256), smem, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);

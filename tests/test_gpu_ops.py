@@ -378,6 +378,12 @@ def test_scale_add_head_frame_layouts(dev):
         if logsm:
             want = F.log_softmax(want, dim=1)
         assert maxdiff(ops.head(p.to(dev), wf.to(dev), bf.to(dev), logsm), want) <= 1e-4
+    for C, n_cls, logsm in ((128, 19, True), (8, 3, True), (20, 12, False)):          # wider / narrower features; C % 8 != 0 takes the generic kernel
+        p = rnd(157, 1, 9, 37, C)
+        wf, bf = rnd(158, n_cls, C, scale=0.2), rnd(159, n_cls, scale=0.1)
+        want = F.conv2d(p.permute(0, 3, 1, 2), wf[:, :, None, None], bf)
+        want = F.log_softmax(want, dim=1) if logsm else want
+        assert maxdiff(ops.head(p.to(dev), wf.to(dev), bf.to(dev), logsm), want) <= 1e-4
     # frame ingest with and without downscale
     img = rnd(60, 2, 3, 20, 30)
     same = ops.frame_to_nhwc4(img.to(dev), 20, 30).cpu()
