@@ -242,6 +242,79 @@ __global__ __launch_bounds__(256) void head16_kernel(const uint16_t *__restrict_
     }
 }
 
+// The same head on the fp32 matrix cores (see head_mfma_kernel in layers.hip): D[class][pixel] per 32-pixel tile of a wave, the 16-bit
+// pixel tile converted to fp32 while it is staged through LDS in 64-channel chunks (C % 64 == 0), fp32 weights resident in LDS.  The
+// one-thread-per-pixel kernel above re-reads every weight from LDS per pixel (1200 ds_read_b128 per pixel at C = 256, 19 classes).
+template <bool BF>
+__global__ __launch_bounds__(256) void head16_mfma_kernel(const uint16_t *__restrict__ p, int p_ld, const float *__restrict__ wf, const float *__restrict__ bf,
+                                                          float *__restrict__ logits, int N, int HW, int C, int n_cls, int log_softmax) {
+    constexpr int KC = 64, PS = KC + 4;
+    extern __shared__ __attribute__((aligned(16))) float hsm[];
+    const int WS = C + 4;
+    float *Wl = hsm;                                        // [32][WS] (rows >= n_cls zero)
+    float *Bl = Wl + 32 * WS;                               // [32] bias
+    float *Pl = Bl + 32 + (threadIdx.x >> 6) * 32 * PS;     // this wave's pixel tile chunk [32][PS]
+    const int tid = threadIdx.x, lane = tid & 63, li = lane & 31, lh = lane >> 5, c4n = C >> 2;
+    for (int i = tid; i < 32 * c4n; i += 256) {
+        const int r = i / c4n, c = (i - r * c4n) * 4;
+        *reinterpret_cast<f32x4 *>(Wl + r * WS + c) = r < n_cls ? *reinterpret_cast<const f32x4 *>(wf + (size_t)r * C + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (tid < 32) Bl[tid] = tid < n_cls ? bf[tid] : 0.f;
+    __syncthreads();
+    const long long total = (long long)N * HW, ntile = (total + 31) / 32;
+    for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntile; tile += (long long)gridDim.x * 4) {
+        const long long px0 = tile * 32;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int kc = 0; kc < C; kc += KC) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                   // 32 pixels x 8 pieces of 8 halves: consecutive lanes, consecutive 16-byte pieces
+                const int i = lane + 64 * j, r = i >> 3, c = (i & 7) * 8;
+                float f[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (px0 + r < total) unpack8<BF>(ld8(p + (size_t)(px0 + r) * p_ld + kc + c), f);
+                *reinterpret_cast<f32x4 *>(Pl + r * PS + c) = f32x4{f[0], f[1], f[2], f[3]};
+                *reinterpret_cast<f32x4 *>(Pl + r * PS + c + 4) = f32x4{f[4], f[5], f[6], f[7]};
+            }
+            const float *wa = Wl + li * WS + kc + lh * (KC / 2), *pb = Pl + li * PS + lh * (KC / 2);
+#pragma unroll
+            for (int k = 0; k < KC / 2; k += 4) {
+                const f32x4 a = *reinterpret_cast<const f32x4 *>(wa + k), b = *reinterpret_cast<const f32x4 *>(pb + k);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], b[e], acc, 0, 0, 0);
+            }
+        }
+        float m = -INFINITY;                                // lane = pixel li; acc[r] = class (r&3) + 8*(r>>2) + 4*lh
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cls = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            acc[r] += Bl[cls];
+            m = fmaxf(m, cls < n_cls ? acc[r] : -INFINITY);
+        }
+        if (log_softmax) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+            m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            float z = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z += (r & 3) + 8 * (r >> 2) + 4 * lh < n_cls ? expf(acc[r] - m) : 0.f;
+            auto sz = __builtin_amdgcn_permlane32_swap(__float_as_uint(z), __float_as_uint(z), false, false);
+            const float lse = m + logf(__uint_as_float(sz[0]) + __uint_as_float(sz[1]));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] -= lse;
+        }
+        const long long pix = px0 + li;
+        if (pix < total) {
+            const int n = (int)(pix / HW);
+            const long long hw = pix - (long long)n * HW;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cls = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (cls < n_cls) logits[((size_t)n * n_cls + cls) * HW + hw] = acc[r];
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ element type conversion (fp32 <-> 16-bit), 8 elements per thread
 template <bool BF>
 __global__ __launch_bounds__(256) void cast_to32_kernel(const uint16_t *__restrict__ in, float *__restrict__ out, long long n8) {
@@ -402,11 +475,26 @@ extern "C" int arseg_head16_fwd(const void *p, int p_ld, int dtype, const float 
     ARSEG_CHECK_PTR(p); ARSEG_CHECK_PTR(wf); ARSEG_CHECK_PTR(bf); ARSEG_CHECK_PTR(logits); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(HW); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(n_cls);
     if ((C & 7) || (p_ld & 7) || p_ld < C || !ARSEG_ALIGNED16(p)) return ARSEG_EINVAL;
     if (n_cls > 32) return ARSEG_EUNSUPPORTED;
+    hipStream_t st = arseg_stream(stream);
+    const uint16_t *pp = (const uint16_t *)p;
+    if (!(C & 63) && C <= 512 && ARSEG_ALIGNED16(wf)) {          // fp32 matrix-core kernel, 64-channel chunks
+        const size_t sm = (size_t)(32 * (C + 4) + 32 + 4 * 32 * 68) * sizeof(float);
+        static ArsegSmemAttr attr_bf, attr_h;
+        const long long ntile = ((long long)N * HW + 31) / 32;
+        const long long gb = (ntile + 3) / 4;
+        const dim3 grid((unsigned)(gb > 2048 ? 2048 : gb));
+        if (dtype == ARSEG_DT_BF16) {
+            if (int e = arseg_allow_smem(attr_bf, reinterpret_cast<const void *>(head16_mfma_kernel<true>), sm)) return e;
+            hipLaunchKernelGGL(head16_mfma_kernel<true>, grid, dim3(256), sm, st, pp, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        } else if (dtype == ARSEG_DT_F16) {
+            if (int e = arseg_allow_smem(attr_h, reinterpret_cast<const void *>(head16_mfma_kernel<false>), sm)) return e;
+            hipLaunchKernelGGL(head16_mfma_kernel<false>, grid, dim3(256), sm, st, pp, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        } else return ARSEG_EINVAL;
+        return arseg_launch_status();
+    }
     const size_t smem = (size_t)n_cls * C * sizeof(float);
     if (smem > 64 * 1024) return ARSEG_EUNSUPPORTED;
     const int g = grid_for((long long)N * HW, 2048);
-    hipStream_t st = arseg_stream(stream);
-    const uint16_t *pp = (const uint16_t *)p;
 #define HEAD(BF_) do { if (n_cls <= 12) hipLaunchKernelGGL((head16_kernel<BF_, 12>), dim3(g), dim3(256), smem, st, pp, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax); \
                        else if (n_cls <= 19) hipLaunchKernelGGL((head16_kernel<BF_, 19>), dim3(g), dim3(256), smem, st, pp, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax); \
                        else hipLaunchKernelGGL((head16_kernel<BF_, 32>), dim3(g), dim3(256), smem, st, pp, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax); } while (0)

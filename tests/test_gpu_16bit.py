@@ -131,6 +131,12 @@ def test_small_layers16(dev, dtype):
     wf, bf = rnd(14, 19, 64, scale=0.2), rnd(15, 19, scale=0.1)
     lg = ops.head(xd, wf.to(dev), bf.to(dev), log_softmax=False)
     assert lg.dtype == torch.float32 and maxdiff(lg, F.conv2d(xc, wf.double()[:, :, None, None], bf.double())) <= 1e-4
+    for C2, ncls2, lsm in ((256, 19, True), (128, 12, False), (24, 5, True)):          # chunked matrix-core kernel (C % 64 == 0) / generic kernel
+        x2 = rnd(17, 1, 9, 37, C2).to(dtype)
+        wf2, bf2 = rnd(18, ncls2, C2, scale=0.2), rnd(19, ncls2, scale=0.1)
+        want2 = F.conv2d(x2.double().permute(0, 3, 1, 2), wf2.double()[:, :, None, None], bf2.double())
+        want2 = F.log_softmax(want2, dim=1) if lsm else want2
+        assert maxdiff(ops.head(x2.to(dev), wf2.to(dev), bf2.to(dev), log_softmax=lsm), want2) <= 2e-4
     # frame ingest (+ downscale) and casts
     img = rnd(16, 2, 3, 36, 48)
     want = F.interpolate(img.double(), (18, 24), mode="bilinear", align_corners=True).permute(0, 2, 3, 1)
