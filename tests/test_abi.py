@@ -208,3 +208,26 @@ def test_reference_attention_imports_with_shim():
         "print('ok')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/arseg_hip.h must be consumable from C (the boundary is a C ABI: cgo / JNI / ctypes style bindings): a C99 translation
+    unit including it compiles with -pedantic, links against the library and calls host-only entry points."""
+    import shutil
+    import subprocess
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    src = tmp_path / "use.c"
+    src.write_text('#include "arseg_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { arseg_conv_desc d; (void)d;\n'
+                   '  if (arseg_conv2d_find(0,0,0,0,0,0,0,0,0,0,0,0,0,0) != ARSEG_EINVAL) return 2;\n'
+                   '  if (arseg_packed_k(64, 3, 3) != 576) return 3;\n'
+                   '  printf("%d %s\\n", arseg_version(), arseg_status_string(ARSEG_EUNSUPPORTED)); return 0; }\n')
+    libdir = os.path.join(ROOT, "ar-seg_amd", "lib")
+    exe = tmp_path / "use"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L", libdir, "-larseg_hip", f"-Wl,-rpath,{libdir}"], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    assert int(out[0]) >= 1
