@@ -1054,21 +1054,45 @@ extern "C" int arseg_conv2d_find(const arseg_conv_desc *d, const float *in, cons
     arseg_conv_desc t = *d;
     float best = -1.0f;
     int first_err = ARSEG_EUNSUPPORTED;
+    float tms[128];                                   // per candidate: ms for `reps` launches, < 0 = not launched
+    auto time_cand = [&](int i, int nrep, float *ms) -> int {
+        t.tile_cfg = c[i].cfg; t.split_k = c[i].sk;
+        int st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);      // warm
+        if (st != ARSEG_OK) return st;
+        (void)hipEventRecord(e0, hs);
+        for (int r = 0; r < nrep; ++r) st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);
+        (void)hipEventRecord(e1, hs);
+        if (hipEventSynchronize(e1) != hipSuccess) { const int e = (int)hipGetLastError(); return e ? e : ARSEG_EINVAL; }
+        (void)hipEventElapsedTime(ms, e0, e1);
+        *ms /= (float)nrep;
+        return st;
+    };
     for (int i = 0; i < n; ++i) {
+        tms[i] = -1.0f;
         t.tile_cfg = c[i].cfg; t.split_k = c[i].sk;
         if (arseg_conv2d_workspace_bytes(&t) > workspace_bytes) continue;
-        int st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);      // warm
-        if (st != ARSEG_OK) { if (i == 0) first_err = st; continue; }
-        (void)hipEventRecord(e0, hs);
-        for (int r = 0; r < reps; ++r) st = arseg_conv2d_fwd(&t, in, w_packed, scale, bias, residual, out, workspace, workspace_bytes, stream);
-        (void)hipEventRecord(e1, hs);
-        if (hipEventSynchronize(e1) != hipSuccess) { st = (int)hipGetLastError(); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st ? st : ARSEG_EINVAL; }
         float ms = 0.0f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (st == ARSEG_OK && (best < 0.0f || ms < best)) { best = ms; *tile_cfg = c[i].cfg; *split_k = c[i].sk; }
+        const int st = time_cand(i, reps, &ms);
+        if (st > 0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
+        if (st != ARSEG_OK) { if (i == 0) first_err = st; continue; }
+        tms[i] = ms;
+        if (best < 0.0f || ms < best) { best = ms; *tile_cfg = c[i].cfg; *split_k = c[i].sk; }
+    }
+    // second look at the candidates within 10 % of the fastest, 4x the repetitions: a single short measurement of a 20 us kernel is
+    // noisy enough to pick a plan that is 5-10 % slower in steady state (seen as run-to-run spread of the whole step)
+    if (best > 0.0f) {
+        const float lim = best * 1.10f;
+        float best2 = -1.0f;
+        for (int i = 0; i < n; ++i) {
+            if (tms[i] < 0.0f || tms[i] > lim) continue;
+            float ms = 0.0f;
+            if (time_cand(i, 4 * reps, &ms) != ARSEG_OK) continue;
+            if (best2 < 0.0f || ms < best2) { best2 = ms; *tile_cfg = c[i].cfg; *split_k = c[i].sk; }
+        }
+        if (best2 > 0.0f) best = best2;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (best < 0.0f) return first_err;          // nothing could be launched (e.g. the 2 GiB limit of the 32-bit buffer offsets)
-    if (best_us) *best_us = best * 1000.0f / (float)reps;
+    if (best_us) *best_us = best * 1000.0f;
     return ARSEG_OK;
 }
