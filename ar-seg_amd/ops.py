@@ -680,7 +680,7 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
 _WINOGRAD = os.environ.get("ARSEG_CONV_WINOGRAD", "1") != "0"
 
 
-def _time(fn, reps=3):
+def _time(fn, reps=6):
     fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
