@@ -210,6 +210,9 @@ int arseg_conv2d_find(const arseg_conv_desc *d, const float *in, const float *w_
  *   M[36][T][Cout] = 36 GEMMs V[k] x U[k]^T                   arseg_conv2d_fwd in batched mode (batch = 36, 1x1)
  *   out NHWC       = arseg_wino43_output_fwd(M) with the usual scale / bias / residual / activation epilogue
  * U = arseg_wino43_pack_weight_host(w OIHW) -> [36][Cout][Cin] (Cin % 32 == 0 so that it is a valid packed 1x1 weight).
+ * Operand range under ARSEG_MATH_F16X3: the GEMM operands are the TRANSFORMED activations V = B^T d B, up to 100x (typically ~10x) the
+ * activations, so the split-fp16 range (|V| <= 131008) is reached for |x| >~ 1.3e3 in the worst case; beyond it V clamps.  Layers whose
+ * inputs can be that large (no normalisation in front) should use the direct plans (ops: ARSEG_CONV_WINOGRAD=0) or ARSEG_MATH_F32.
  * 2.25x..4x fewer MACs than the direct form; fp32 rounding error ~1e-5 relative instead of ~1e-6. */
 long long arseg_wino43_tiles(int N, int H, int W, int dil);
 /* upsample2x != 0: `in` is the low-resolution tensor [N,H/2,W/2,C] and the x2 bilinear (align_corners=False) upsample of
