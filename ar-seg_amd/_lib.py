@@ -59,8 +59,8 @@ PROTOTYPES = {
     "arseg_conv2d_find_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
     "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
-    "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
-    "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
+    "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
+    "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _STREAM]),
     "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),
     "arseg_packed_k": (c_int, [c_int, c_int, c_int]),
     "arseg_pack_conv_weight_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),

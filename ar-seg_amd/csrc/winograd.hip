@@ -59,7 +59,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // F = float (any C) or f32x2 (C even, 8-byte aligned rows): channels per thread
 template <typename F>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
-                                                           WinoGeom g) {
+                                                           WinoGeom g, float vscale) {
     constexpr int VW = sizeof(F) / sizeof(float);
     const int Cv = C / VW, total = g.T * Cv;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
             F r[6];
             bt6(tmp[i], r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j] * vscale;
         }
     }
 }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
 // border handling exactly (src < 0 -> 0; i1 = min(i0+1, h-1)).  Dilation 1 only.
 template <typename F>
 __global__ __launch_bounds__(256) void wino43_input_up2_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
-                                                               WinoGeom g) {
+                                                               WinoGeom g, float vscale) {
     constexpr int VW = sizeof(F) / sizeof(float);
     const int Cv = C / VW, total = g.T * Cv, h = g.H >> 1, w = g.W >> 1;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void wino43_input_up2_kernel(const float *__re
             F r[6];
             bt6(tmp[i], r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j];
+            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j] * vscale;
         }
     }
 }
@@ -174,7 +174,7 @@ __device__ __forceinline__ float wino_act(float v, int act, float slope) {
 template <typename F>
 __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restrict__ M, const float *__restrict__ scale,
                                                             const float *__restrict__ bias, const float *__restrict__ res, int res_ld,
-                                                            float *__restrict__ out, int out_ld, int C, int act, float slope, WinoGeom g) {
+                                                            float *__restrict__ out, int out_ld, int C, int act, float slope, WinoGeom g, float mscale) {
     constexpr int VW = sizeof(F) / sizeof(float);
     const int Cv = C / VW, total = g.T * Cv;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restr
                 const int ox = x0 + g.d * j;
                 if (ox >= g.W) continue;
                 const size_t pix = ((size_t)n * g.H + oy) * g.W + ox;
-                F v = y[j] * sc + bi;
+                F v = (y[j] * mscale) * sc + bi;
                 if (res) v += *reinterpret_cast<const F *>(res + pix * res_ld + c);
                 float *vp = reinterpret_cast<float *>(&v);
 #pragma unroll
@@ -235,7 +235,8 @@ extern "C" long long arseg_wino43_tiles(int N, int H, int W, int dil) {
 }
 
 extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
-                                      arseg_stream_t stream) {
+                                      float v_scale, arseg_stream_t stream) {
+    if (!(v_scale > 0.0f)) return ARSEG_EINVAL;
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(V); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(dil);
     if (in_ld < C) return ARSEG_EINVAL;
     if (upsample2x && (dil != 1 || (H & 1) || (W & 1))) return ARSEG_EUNSUPPORTED;
@@ -244,19 +245,19 @@ extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int 
     const WinoGeom g = make_geom(N, H, W, dil);
     const bool vec2 = !(C & 1) && !(in_ld & 1) && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(V) & 7);
     if (upsample2x) {
-        if (vec2) hipLaunchKernelGGL(wino43_input_up2_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
-        else hipLaunchKernelGGL(wino43_input_up2_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+        if (vec2) hipLaunchKernelGGL(wino43_input_up2_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
+        else hipLaunchKernelGGL(wino43_input_up2_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
         return arseg_launch_status();
     }
     if (vec2)
-        hipLaunchKernelGGL(wino43_input_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+        hipLaunchKernelGGL(wino43_input_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
     else
-        hipLaunchKernelGGL(wino43_input_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g);
+        hipLaunchKernelGGL(wino43_input_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
     return arseg_launch_status();
 }
 
 extern "C" int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
-                                       int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, arseg_stream_t stream) {
+                                       int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(M); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Cout); ARSEG_CHECK_POS(dil);
     if (out_ld < Cout || (residual && res_ld < Cout)) return ARSEG_EINVAL;
     const long long T = arseg_wino43_tiles(N, H, W, dil);
@@ -265,10 +266,10 @@ extern "C" int arseg_wino43_output_fwd(const float *M, const float *scale, const
     auto al8 = [](const void *p) { return !(reinterpret_cast<uintptr_t>(p) & 7); };
     if (!(Cout & 1) && !(out_ld & 1) && !(res_ld & 1) && al8(M) && al8(out) && al8(scale) && al8(bias) && al8(residual))
         hipLaunchKernelGGL(wino43_output_kernel<f32x2>, dim3(grid_for((long long)g.T * Cout / 2)), dim3(256), 0, arseg_stream(stream), M, scale,
-                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
+                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g, m_scale);
     else
         hipLaunchKernelGGL(wino43_output_kernel<float>, dim3(grid_for((long long)g.T * Cout)), dim3(256), 0, arseg_stream(stream), M, scale,
-                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g);
+                           bias, residual, res_ld, out, out_ld, Cout, act, prelu_slope, g, m_scale);
     return arseg_launch_status();
 }
 

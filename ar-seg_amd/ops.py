@@ -700,7 +700,10 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     V = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)
     M = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
     la = _launch if record else (lambda name, fn, *a, **k: check(fn(*a), name))
-    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, _stream())
+    # under f16x3 the transformed activations are stored scaled by 2^-4 (exact; undone in the output transform): B^T d B amplifies by up to
+    # 100, and unscaled the split-fp16 operand range would be left for |x| >~ 1.3e3
+    vs = 2.0 ** -4 if _math == _lib.MATH_F16X3 else 1.0
+    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs, _stream())
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.in_ld = 1, T, 1, Cin, Cin
     d.Cout, d.out_ld, d.res_ld = Cout, Cout, Cout
@@ -733,7 +736,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
         plan = _conv_plans[key] = best
     gemm(plan, record)
     la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual),
-       _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, _stream())
+       _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, 1.0 / vs, _stream())
 
 
 def _tune_conv(launch, pc, m):

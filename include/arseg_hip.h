@@ -211,16 +211,21 @@ int arseg_conv2d_find(const arseg_conv_desc *d, const float *in, const float *w_
  *   out NHWC       = arseg_wino43_output_fwd(M) with the usual scale / bias / residual / activation epilogue
  * U = arseg_wino43_pack_weight_host(w OIHW) -> [36][Cout][Cin] (Cin % 32 == 0 so that it is a valid packed 1x1 weight).
  * Operand range under ARSEG_MATH_F16X3: the GEMM operands are the TRANSFORMED activations V = B^T d B, up to 100x (typically ~10x) the
- * activations, so the split-fp16 range (|V| <= 131008) is reached for |x| >~ 1.3e3 in the worst case; beyond it V clamps.  Layers whose
- * inputs can be that large (no normalisation in front) should use the direct plans (ops: ARSEG_CONV_WINOGRAD=0) or ARSEG_MATH_F32.
+ * activations, so unscaled the split-fp16 range (|V| <= 131008) is reached for |x| >~ 1.3e3 in the worst case (beyond it V clamps): pass
+ * v_scale = 2^-4 / m_scale = 2^4 (what the Python layer does) to move the limit to |x| ~ 2e4 worst case; the price is the absolute
+ * floor of the low fp16 half (subnormal step 2^-24) rising to 2^-20 in units of V, still below Winograd's own fp32 rounding for O(1) data.
  * 2.25x..4x fewer MACs than the direct form; fp32 rounding error ~1e-5 relative instead of ~1e-6. */
 long long arseg_wino43_tiles(int N, int H, int W, int dil);
 /* upsample2x != 0: `in` is the low-resolution tensor [N,H/2,W/2,C] and the x2 bilinear (align_corners=False) upsample of
  * PSPUpsample (model/pspnet.py:45) is applied on the fly (H, W = upsampled size, even; dil == 1). */
-int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
+/* v_scale / m_scale: V is stored multiplied by v_scale (> 0), M is multiplied by m_scale before the epilogue; with powers of two and
+ * m_scale = 1 / v_scale the result is unchanged bit for bit while the GEMM operands shrink -- under ARSEG_MATH_F16X3 the transformed
+ * activations (up to 100x, typically ~10x the input) otherwise leave the split-fp16 range for |x| >~ 1.3e3.  1.0f = no scaling. */
+int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x, float v_scale,
                            arseg_stream_t stream);
 int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
-                            int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, arseg_stream_t stream);
+                            int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale,
+                            arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
 
 /* Host-side weight preparation (the "weight packer"; CPU pointers).
