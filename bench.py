@@ -103,11 +103,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # ARSEG_DIST_BACKEND=gloo: rehearsal of the N-rank schedule on a box with fewer GPUs than ranks (ranks share devices, the exchange
+    # goes through gloo) -- exercises everything of the multi-rank path except RCCL itself; never a measurement
+    backend = os.environ.get("ARSEG_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from arseg_amd import _lib, evaluation as ev, ops, synth
     from arseg_amd.gop import GopRunner
@@ -390,6 +398,8 @@ def main():
                             "tolerance": 1e-3}
         if fused_tail:
             result["parity"]["fused_tail_label_agreement"] = float((pred0 == o_out.argmax(1)).float().mean())
+    if world > 1 and backend != "nccl":
+        result["rehearsal"] = f"backend {backend}, {world} ranks on {torch.cuda.device_count()} GPU(s): schedule check, not a measurement"
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
