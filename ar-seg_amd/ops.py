@@ -562,6 +562,9 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     def launch_wino(record=True):
         _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
 
+    def launch_taps(record=True):
+        _conv_up2_taps(x_low, pc, out, record)
+
     def find_native():
         """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
         fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
@@ -580,8 +583,10 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
         key = (dev.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
         wino_ok = getattr(pc, "wino_u", None) is not None and _WINOGRAD
+        taps_ok = (x_low is not None and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
+                   and pc.dil == 1 and pc.cout % 4 == 0)
         plan = _conv_plans.get(key)
-        if plan == "wino" and not wino_ok:                      # a persisted Winograd plan with ARSEG_CONV_WINOGRAD=0: re-tune
+        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok):      # a persisted plan whose route is switched off: re-tune
             plan = None
         if plan is None:
             plan = find_native() if _NATIVE_FIND else None
@@ -604,9 +609,19 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "wino"
                 except _lib.ArsegError:
                     pass                                        # the Winograd route does not cover this shape: keep the direct plan
+            if taps_ok:
+                try:
+                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: launch(*plan, record=False)))
+                    launch_taps(record=False)                   # tunes the low-resolution GEMM underneath
+                    if _time(lambda: launch_taps(record=False)) < t_best:
+                        plan = "taps"
+                except _lib.ArsegError:
+                    pass
             _conv_plans[key] = plan
         if plan == "wino":
             launch_wino()
+        elif plan == "taps":
+            launch_taps()
         else:
             launch(*plan)
     else:
@@ -737,6 +752,23 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     gemm(plan, record)
     la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual),
        _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, 1.0 / vs, _stream())
+
+
+_UP2_TAPS = os.environ.get("ARSEG_CONV_UP2_TAPS", "1") != "0"
+
+
+def _conv_up2_taps(x_low, pc, out, record=True):
+    """conv3x3(pad 1) of the x2 bilinear upsample of ``x_low`` by tap decomposition (csrc/upconv.hip): one 1x1 conv at low resolution
+    with the nine taps stacked along the output channels, then the gather that samples the nine planes at the shifted positions of the
+    upsampled image and applies the epilogue of ``pc``."""
+    lib = _lib.load()
+    n, h, w, _ = x_low.shape
+    z = conv2d(x_low, pc.taps())
+    args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, pc.cout, pc.act, pc.slope, _stream())
+    if record:
+        _launch("up2_tap_gather", lib.arseg_upconv3x3_tap_gather_fwd, *args)
+    else:
+        check(lib.arseg_upconv3x3_tap_gather_fwd(*args), "up2_tap_gather")
 
 
 def _tune_conv(launch, pc, m):

@@ -93,6 +93,17 @@ class PackedConv:
             cache[dtype] = (torch.from_numpy(packed.view(np.int16)).to(self.w.device).view(dtype), cin_pad)
         return cache[dtype]
 
+    def taps(self):
+        """The nine taps of a 3x3 conv stacked along the output channels of ONE 1x1 conv (row t*Cout + co = W[co][.][t//3][t%3], no
+        epilogue): the low-resolution GEMM of the tap-decomposed conv-after-upsample route (arseg_upconv3x3_tap_gather_fwd).  Built on
+        first use."""
+        if "_taps" not in self.__dict__:
+            if self.R != 3 or self.S != 3:
+                raise _lib.ArsegError("taps(): 3x3 convs only")
+            w9 = np.ascontiguousarray(self._w_oihw.transpose(2, 3, 0, 1).reshape(9 * self.cout, self.cin, 1, 1))
+            self._taps = PackedConv(w9, None, None, 1, 0, 1, _lib.ACT_NONE, 0.0, self.w.device)
+        return self._taps
+
     @staticmethod
     def from_modules(conv, bn=None, act=_lib.ACT_NONE, slope=0.0, device="cuda"):
         """conv: nn.Conv2d or nn.Linear; bn: nn.BatchNorm2d or None."""

@@ -259,8 +259,8 @@ def main():
         tot_flops = conv["flops"] / 3 + conv_k["flops"]
         tot_ms = conv["ms"] / 3 + conv_k["ms"]
         n_launch = conv["launches"] / 3 + conv_k["launches"]
-        wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output")) / 3 + \
-            sum(ky.get(k, {"ms": 0.0})["ms"] for k in ("wino_input", "wino_output"))
+        aux = ("wino_input", "wino_output", "up2_tap_gather")      # memory-bound passes that belong to a conv: Winograd transforms, tap gather
+        wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in aux) / 3 + sum(ky.get(k, {"ms": 0.0})["ms"] for k in aux)
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9
         mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]
         if storage != "f32":
@@ -288,8 +288,9 @@ def main():
             "executed_gemm_tflops": gemm_tf,
             "per_launch": {"avg_gemm_flops": tot_flops / n_launch, "avg_ms": tot_ms / n_launch, "launches_per_step": n_launch},
             "note": "achieved = SURVEY 8d algorithmic FLOPs of one GOP step / summed conv-kernel time of that step (HIP events on the launch stream); "
-                    "executed_gemm_tflops = the fp32 GEMM FLOPs the kernels execute (Winograd and the folded pyramid execute fewer than the "
-                    "reference's direct convs); mfma_issue_frac counts each of those three times (the hi/lo emulation)",
+                    "executed_gemm_tflops = the fp32 GEMM FLOPs the kernels execute (Winograd, the tap-decomposed upsample convs and the folded "
+                    "pyramid execute fewer than the reference's direct convs); winograd_transform_ms_per_step also holds the tap-gather pass "
+                    "of the upsample convs; mfma_issue_frac counts each of those three times (the hi/lo emulation)",
         }
         # ---- dominant kernel of the step (rocprofv3 kernel stats, profiles/r02_*_kernel_stats.csv): the warp + CReFF stage, HBM-bound by the
         # SURVEY 8d accounting.  B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe; one launch = this rank's

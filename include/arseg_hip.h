@@ -226,6 +226,16 @@ int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, i
 int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
                             int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale,
                             arseg_stream_t stream);
+
+/* conv3x3 (pad 1, stride 1) of a x2 bilinear (align_corners=False) upsample -- PSPUpsample, /root/reference/model/pspnet.py:43-46 --
+ * by tap decomposition: since a 1x1 conv commutes with a per-channel resize, conv3x3(Up(x)) = sum_t shift_t(Up(W_t x)).  The caller
+ * runs ONE 1x1 conv at low resolution with the nine taps stacked along the output channels (weights [9*Cout][Cin], row t*Cout + co =
+ * W[co][.][t/3][t%3]; arseg_conv2d_fwd, no epilogue) into z = [N,h,w,9*Cout] (row stride z_ld), and this entry point samples the nine
+ * planes at the shifted positions of the never-materialised upsampled image (zero outside it = the conv's padding), sums them and applies
+ * out = act(scale * sum + bias) into out = [N,2h,2w,Cout].  Same multiply count as Winograd F(4x4,3x3) on the upsampled image, without
+ * its transformed operand (9x the low-resolution input) and without its rounding amplification.  Cout % 4 == 0, 16-byte aligned. */
+int arseg_upconv3x3_tap_gather_fwd(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N, int h,
+                                   int w, int Cout, int act, float prelu_slope, arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
 
 /* Host-side weight preparation (the "weight packer"; CPU pointers).

@@ -516,6 +516,11 @@ def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     assert maxdiff(out.permute(0, 3, 1, 2), want) <= 2e-4
     got = ops.conv2d(xd, pc, up2=True)                      # autotuned choice
     assert maxdiff(got.permute(0, 3, 1, 2), want) <= 2e-4
+    # tap decomposition (csrc/upconv.hip): nine 1x1 taps at low resolution + the gather over the upsampled positions; no transform, so it is
+    # held to the direct form's tolerance
+    outt = torch.full((N, 2 * h, 2 * w, Cout), float("nan"), device=dev)
+    ops._conv_up2_taps(xd, pc, outt)
+    assert maxdiff(outt.permute(0, 3, 1, 2), want) <= 5e-5
     got2 = ops.conv2d(xd, pc, up2=True, tile_cfg=7, split_k=1)   # forced direct
     assert maxdiff(got2.permute(0, 3, 1, 2), want) <= 2e-4
     if conv_math == "f16x3":
