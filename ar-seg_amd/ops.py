@@ -586,7 +586,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         taps_ok = (x_low is not None and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
                    and pc.dil == 1 and pc.cout % 4 == 0)
         plan = _conv_plans.get(key)
-        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok):      # a persisted plan whose route is switched off: re-tune
+        if (plan == "wino" and not wino_ok) or (plan in ("taps", "tapsf") and not taps_ok) or (plan == "tapsf" and not _UP2_FUSED):      # a persisted plan whose route is switched off: re-tune
             plan = None
         if plan is None:
             plan = find_native() if _NATIVE_FIND else None
@@ -617,9 +617,19 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "taps"
                 except _lib.ArsegError:
                     pass
+            if taps_ok and _UP2_FUSED and Cin == 64 and pc.cout % 16 == 0 and math == _lib.MATH_F16X3:
+                try:
+                    t_best = _time({"wino": lambda: launch_wino(record=False), "taps": lambda: launch_taps(record=False)}.get(
+                        plan, lambda: launch(*plan, record=False)))
+                    if _time(lambda: _conv_up2_fused(x_low, pc, out, record=False)) < t_best:
+                        plan = "tapsf"
+                except _lib.ArsegError:
+                    pass
             _conv_plans[key] = plan
         if plan == "wino":
             launch_wino()
+        elif plan == "tapsf":
+            _conv_up2_fused(x_low, pc, out)
         elif plan == "taps":
             launch_taps()
         else:
@@ -755,6 +765,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
 
 
 _UP2_TAPS = os.environ.get("ARSEG_CONV_UP2_TAPS", "1") != "0"
+_UP2_FUSED = os.environ.get("ARSEG_CONV_UP2_FUSED", "0") == "1"      # LDS-resident tap planes for 64 input channels: on par with the direct plan, opt-in
 
 
 def _conv_up2_taps(x_low, pc, out, record=True):
@@ -769,6 +780,21 @@ def _conv_up2_taps(x_low, pc, out, record=True):
         _launch("up2_tap_gather", lib.arseg_upconv3x3_tap_gather_fwd, *args)
     else:
         check(lib.arseg_upconv3x3_tap_gather_fwd(*args), "up2_tap_gather")
+
+
+def _conv_up2_fused(x_low, pc, out, record=True):
+    """The tap decomposition with the tap planes kept in LDS (arseg_upconv3x3_fused_fwd): 64 input channels, f16x3 arithmetic."""
+    if _math != _lib.MATH_F16X3:
+        raise _lib.ArsegError("fused tap route: f16x3 arithmetic only")
+    lib = _lib.load()
+    n, h, w, cin = x_low.shape
+    pt = pc.taps()
+    args = (_ptr(x_low), _nhwc_ld(x_low), _ptr(pt.w_h3), _ptr(pt.scale_h3), _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, cin,
+            pc.cout, pc.act, pc.slope, _stream())
+    if record:
+        _launch("conv2d", lib.arseg_upconv3x3_fused_fwd, *args, flops=2 * n * h * w * cin * 9 * pc.cout)
+    else:
+        check(lib.arseg_upconv3x3_fused_fwd(*args), "upconv3x3_fused")
 
 
 def _tune_conv(launch, pc, m):
