@@ -87,8 +87,8 @@ def build_nets(dev, cfg):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the (slow) CPU oracle leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
