@@ -199,6 +199,42 @@ __global__ __launch_bounds__(256) void resize_nchw_bilinear_x4_kernel(const floa
     }
 }
 
+// The same resize for an exact x8 / x16 horizontal factor with align_corners=False (the BiSeNetOutput upsamples): the S outputs
+// x in [S*j + S/2, S*j + 3S/2) share their two source columns (j, j+1; clamped at the borders, where the run is half as long), so a thread
+// takes one run of one output row: 4 loads and S/4 16-byte stores instead of 16 loads and the index arithmetic per store.  Each value is
+// the expression of the kernel above on the same taps and the same lx (computed per element the same way): identical results.
+template <int S>
+__global__ __launch_bounds__(256) void resize_nchw_bilinear_runs_kernel(const float *__restrict__ in, float *__restrict__ out, int NC, int Hin,
+                                                                        int Win, int Hout) {
+    const int Wout = S * Win, nrun = Win + 1;
+    const long long total = (long long)NC * Hout * nrun;
+    const float sy = arseg_resize_scale(Hin, Hout, false), sx = arseg_resize_scale(Win, Wout, false);
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int jr = (int)(idx % nrun) - 1, oy = (int)((idx / nrun) % Hout);
+        const long long pc = idx / ((long long)nrun * Hout);
+        const float *base = in + (size_t)pc * Hin * Win;
+        int y0, y1; float ly;
+        arseg_src_index(sy, oy, false, Hin, y0, y1, ly);
+        ly = fminf(fmaxf(ly, 0.f), 1.f);
+        const int x0 = max(jr, 0), x1 = min(jr + 1, Win - 1);
+        const float *r0 = base + (size_t)y0 * Win, *r1 = base + (size_t)y1 * Win;
+        const float a0 = r0[x0], a1 = r0[x1], b0 = r1[x0], b1 = r1[x1];
+        const int xs = max(S * jr + S / 2, 0), xe = min(S * jr + 3 * S / 2, Wout);
+        float *o = out + ((size_t)pc * Hout + oy) * Wout;
+        for (int x = xs; x < xe; x += 4) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float src = fmaxf(sx * ((float)(x + e) + 0.5f) - 0.5f, 0.0f);
+                float lx = src - (float)x0;
+                lx = fminf(fmaxf(lx, 0.f), 1.f);
+                v[e] = (1.f - ly) * ((1.f - lx) * a0 + lx * a1) + ly * ((1.f - lx) * b0 + lx * b1);
+            }
+            *reinterpret_cast<f32x4 *>(o + x) = v;
+        }
+    }
+}
+
 // ------------------------------------------------------------------ pyramid priors: sum of bilinear upsamples
 // out[n,y,x,c] = sum_s bilinear(align_corners=False)( t[n, off_s .. off_s + size_s^2, c] reshaped [size_s,size_s] )(y,x)
 struct PriorSizes { int n; int size[4]; int off[4]; int rows; };
@@ -745,7 +781,13 @@ extern "C" int arseg_resize_fwd(const float *in, float *out, int N, int C, int H
         hipLaunchKernelGGL(resize_nhwc_kernel, dim3(grid_for((long long)N * Hout * Wout * (C >> 2))), dim3(256), 0,
                            arseg_stream(stream), in, out, N, C, Hin, Win, Hout, Wout, mode, align_corners ? 1 : 0, in_ld, out_ld);
     } else if (layout == ARSEG_NCHW) {
-        if (mode == ARSEG_BILINEAR && (Wout & 3) == 0 && ARSEG_ALIGNED16(out))
+        if (mode == ARSEG_BILINEAR && !align_corners && (Wout == 8 * Win || Wout == 16 * Win) && ARSEG_ALIGNED16(out)) {
+            const int g = grid_for((long long)N * C * Hout * (Win + 1), 65536);
+            if (Wout == 8 * Win)
+                hipLaunchKernelGGL(resize_nchw_bilinear_runs_kernel<8>, dim3(g), dim3(256), 0, arseg_stream(stream), in, out, N * C, Hin, Win, Hout);
+            else
+                hipLaunchKernelGGL(resize_nchw_bilinear_runs_kernel<16>, dim3(g), dim3(256), 0, arseg_stream(stream), in, out, N * C, Hin, Win, Hout);
+        } else if (mode == ARSEG_BILINEAR && (Wout & 3) == 0 && ARSEG_ALIGNED16(out))
             hipLaunchKernelGGL(resize_nchw_bilinear_x4_kernel, dim3(grid_for((long long)N * C * Hout * (Wout >> 2), 16384)), dim3(256), 0,
                                arseg_stream(stream), in, out, N * C, Hin, Win, Hout, Wout, align_corners ? 1 : 0);
         else

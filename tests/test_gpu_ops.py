@@ -349,7 +349,8 @@ def test_adaptive_avgpool_and_global_reduce(dev, H, W, C, s):
     (6, 8, 12, 16, "bilinear", False), (1, 1, 9, 12, "bilinear", False), (3, 3, 9, 12, "bilinear", False),
     (5, 7, 10, 14, "nearest", False), (10, 18, 9, 17, "bilinear", True), (9, 17, 10, 18, "bilinear", True),
     (16, 32, 128, 256, "bilinear", False), (8, 16, 128, 256, "bilinear", False), (48, 64, 24, 32, "bilinear", True),
-    (7, 9, 7, 9, "bilinear", True), (5, 6, 13, 17, "bilinear", True)])
+    (7, 9, 7, 9, "bilinear", True), (5, 6, 13, 17, "bilinear", True),
+    (3, 1, 24, 16, "bilinear", False), (5, 3, 17, 24, "bilinear", False), (2, 5, 32, 80, "bilinear", False)])      # run-based x8 / x16 kernel: one column, ragged rows
 def test_resize(dev, Hin, Win, Hout, Wout, mode, align):
     from arseg_amd import _lib, ops
 
