@@ -440,6 +440,13 @@ def set_conv_math(name: str) -> str:
     prev = [k for k, v in _MATH_NAMES.items() if v == _math][0]
     _math = _MATH_NAMES[name]
     return prev
+# Optional operand-range guard of the split-fp16 back end (include/arseg_hip.h, ARSEG_MATH_F16X3: |x| <= 131008 for the direct plans,
+# ~2e4 in the worst case for the Winograd route): ARSEG_CONV_RANGE_GUARD=1 checks the amax of every conv input (one reduction + a host
+# sync per conv: a validation mode, not for the steady state -- and not capturable into a HIP graph) and evaluates a layer whose
+# input leaves the range (or holds NaN / Inf) with the fp32 MFMA back end instead.  The networks of this path normalise after every
+# conv (BatchNorm), so their activations stay orders of magnitude inside the range; the guard is for foreign inputs.
+_RANGE_GUARD = os.environ.get("ARSEG_CONV_RANGE_GUARD", "0") == "1"
+_RANGE_LIMIT = 2.0e4
 _PLAN_FILE = os.environ.get("ARSEG_CONV_PLAN_FILE")       # optional: persist tuned plans (skips the trial launches next time)
 
 
@@ -499,6 +506,12 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     if is16(x):
         return _conv2d16(x, pc, residual, out, up2, tile_cfg, split_k)
     _need_gpu(x, residual, out)
+    if _RANGE_GUARD and _math == _lib.MATH_F16X3 and not (float(x.abs().max()) <= _RANGE_LIMIT):      # (NaN compares false)
+        prev = set_conv_math("f32")
+        try:
+            return conv2d(x, pc, residual, out, 0, 0, up2)
+        finally:
+            set_conv_math(prev)
     x_low = None
     if up2:
         x_low = x

@@ -617,6 +617,32 @@ def test_conv2d_f16x3_range_boundaries(dev):
         assert float((ow.permute(0, 3, 1, 2).cpu().double() - ww).abs().max() / ww.abs().max()) <= 5e-5, (lo_, hi_)
 
 
+def test_conv2d_range_guard(dev, monkeypatch):
+    """ARSEG_CONV_RANGE_GUARD: a conv whose input leaves the split-fp16 operand range is evaluated with the fp32 MFMA back end.  Input
+    magnitudes up to 1e6 (beyond the 131008 clamp of the direct plans, far beyond the Winograd route's range): without the guard the
+    result is the conv of the clamped input, with it the result is fp32-grade."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(97))
+    w = rnd(98, 64, 64, 3, 3, scale=0.05)
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    x = t((g.standard_normal((1, 64, 12, 20)) * np.exp(g.uniform(np.log(1e2), np.log(1e6), (1, 64, 12, 20)))).astype(np.float32))
+    want = F.conv2d(x.double(), w.double(), padding=1)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    prev = ops.set_conv_math("f16x3")
+    try:
+        e_off = float((ops.conv2d(xd, pc).permute(0, 3, 1, 2).cpu().double() - want).abs().max() / want.abs().max())
+        monkeypatch.setattr(ops, "_RANGE_GUARD", True)
+        e_on = float((ops.conv2d(xd, pc).permute(0, 3, 1, 2).cpu().double() - want).abs().max() / want.abs().max())
+        small = ops.conv2d(xd * 1e-4, pc)                      # inside the range: the guard leaves the f16x3 plan alone
+        assert ops._math == _lib.MATH_F16X3
+    finally:
+        ops.set_conv_math(prev)
+    assert e_on <= 1e-5 and e_off > 1e-2, (e_on, e_off)
+    assert float((small.permute(0, 3, 1, 2).cpu().double() - want * 1e-4).abs().max() / (want.abs().max() * 1e-4)) <= 1e-5
+
+
 @pytest.mark.parametrize("H,W,h,w", [(36, 48, 18, 24), (35, 47, 17, 23), (20, 30, 20, 30)])
 def test_frame_u8_ingest(dev, H, W, h, w):
     """uint8 HWC -> normalised NHWC4 in one kernel == ToTensor + Normalize + F.interpolate(align_corners=True) of the oracle,
