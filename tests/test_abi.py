@@ -109,6 +109,32 @@ def test_weight_packer_host_functions():
     assert np.array_equal(o, dw.reshape(C, 9).T)
 
 
+def test_packed_conv_taps_layout_and_oracle():
+    """PackedConv.taps(): row t*Cout + co of the stacked 1x1 weights = W[co, :, t//3, t%3] (the layout include/arseg_hip.h documents for
+    arseg_upconv3x3_tap_gather_fwd / arseg_upconv3x3_fused_fwd), and the identity the route rests on, checked on the CPU with torch ops:
+    conv3x3(Up(x)) == sum_t shift_t(Up(W_t x)) with zero padding of the UPSAMPLED image."""
+    from arseg_amd import _lib
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.default_rng(5)
+    cout, cin = 8, 12
+    w = g.standard_normal((cout, cin, 3, 3)).astype(np.float32)
+    pc = PackedConv(torch.from_numpy(w), None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, "cpu")
+    pt = pc.taps()
+    assert (pt.cout, pt.cin, pt.R, pt.S, pt.stride, pt.pad) == (9 * cout, cin, 1, 1, 1, 0)
+    rows = pt.w.numpy()[:, :cin]
+    for t in range(9):
+        assert np.array_equal(rows[t * cout:(t + 1) * cout], w[:, :, t // 3, t % 3])
+    x = torch.from_numpy(g.standard_normal((2, cin, 5, 7)).astype(np.float32)).double()
+    up = lambda a: torch.nn.functional.interpolate(a, scale_factor=2.0, mode="bilinear", align_corners=False)
+    want = torch.nn.functional.conv2d(up(x), torch.from_numpy(w).double(), padding=1)
+    z = torch.nn.functional.conv2d(x, torch.from_numpy(rows.reshape(9 * cout, cin, 1, 1)).double())          # the low-resolution GEMM
+    zu = torch.nn.functional.pad(up(z), (1, 1, 1, 1))                                                        # zero outside the upsampled image
+    H, W = want.shape[-2:]
+    got = sum(zu[:, t * cout:(t + 1) * cout, t // 3:t // 3 + H, t % 3:t % 3 + W] for t in range(9))
+    assert float((got - want).abs().max()) <= 1e-12
+
+
 def test_split_weight_f16x3_host():
     """hi + lo (two fp16 per weight, row pre-scaled by a power of two) reproduces the fp32 weight to ~2^-21 of the row maximum."""
     from arseg_amd import _lib
