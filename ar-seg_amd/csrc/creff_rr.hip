@@ -58,6 +58,15 @@ constexpr float LOG2E = 1.44269504088896340736f;
 #ifndef RR_GB
 #define RR_GB 5       // gather units per later batch
 #endif
+#ifndef RR_PV2
+#define RR_PV2 0      // 1: P.V block-major with four accumulators (see phase 7; measured 1.5 % slower); 0: chunk-major
+#endif
+#ifndef RR_BORDER
+#define RR_BORDER 1
+#endif
+#ifndef RR_DEPHASE
+#define RR_DEPHASE 0
+#endif
 
 struct RRParams {
     const float *ref[MAXN];       // un-warped keyframe feature of each frame, NHWC [Hp][Wp][64]
@@ -65,7 +74,7 @@ struct RRParams {
     const float *lr, *wq, *bq, *wk, *bk, *wv, *bv, *wf, *bf;
     float *p_out, *logits;
     int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout, tiles_x, tiles_y;
-    unsigned p_bytes, l_bytes;
+    unsigned p_bytes, l_bytes, lr_bytes;
     float sy, sx;
     unsigned long long *dbg;
 };
@@ -138,9 +147,10 @@ __device__ __forceinline__ double uniform_f64(double x) {
 __device__ __forceinline__ int key_rec(int b, int k0, int base0) { return base0 + 24 * b + (k0 >= 14 - 2 * b ? 8 : 0); }
 
 #ifdef RR_TIMING
-// dev builds only: wave 0 adds the shader-clock ticks since its previous stamp to dbg[i] (scalar registers, one atomic)
-#define RR_STAMP(i) do { if (__builtin_amdgcn_readfirstlane(tid0 >> 6) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
-        if (tid0 == 0 && p.dbg) atomicAdd(p.dbg + (i), now_ - tprev_); tprev_ = now_; } } while (0)
+// dev builds only: a wave adds the shader-clock ticks since its previous stamp to its dbg row (scalar registers, one atomic)
+// (every wave: dbg[16 * wave + i]; tools/time_phases.py reports wave 0, the mean and the slowest wave of each phase)
+#define RR_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+        if ((tid0 & 63) == 0 && p.dbg) atomicAdd(p.dbg + 16 * (tid0 >> 6) + (i), now_ - tprev_); tprev_ = now_; } while (0)
 #else
 #define RR_STAMP(i) do { } while (0)
 #endif
@@ -201,6 +211,14 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             dma4_glb(p.mv + ((size_t)n_ * p.H * p.W + (size_t)gy * p.W + gx) * 2, lds_addr(TapO) + (unsigned)__builtin_amdgcn_readfirstlane(tq >> 6) * 256u);
     };
     if (t_lo + slot < t_hi) mv_fetch(t_lo + slot);
+#if RR_DEPHASE > 0
+    // Every workgroup walks tiles of equal cost, so all 256 CUs sit in the same phase at the same time: the gather phases of the whole
+    // chip hit the L2s together (and leave them idle together).  Half of each XCD's workgroups start RR_DEPHASE x 8k cycles late.
+    if (slot & 1) {
+#pragma unroll 1
+        for (int i = 0; i < RR_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int tile = t_lo + slot; tile < t_hi; tile += nslot) {
     // Everything derived from the thread id is recomputed per phase from an opaque copy: left alone, LLVM hoists the per-lane
@@ -493,6 +511,10 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
     RR_STAMP(4);
 
     // ------------------------------------------------------------------ phases 4 / 6: key (value) records of the whole region
+    // Interior tiles (every record of the 22 x 22 region inside the image: all but the frame's border tiles) need no padding mask -- a
+    // compare, a scalar and and four selects per row.  With RR_BORDER the row loop stores unmasked records and border tiles (a tile-uniform
+    // branch) zero their out-of-image records afterwards.
+    const bool rec_interior = ty0 >= 3 && tx0 >= 3 && ty0 + TY + 3 <= Hp && tx0 + TX + 3 <= Wp;
     auto conv_records = [&](const float *wt, const float *bs, int kpl) {
         RR_TID(t);
         const int lane = t & 63, r4 = lane >> 4, xi = lane & 15;
@@ -527,14 +549,27 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             acc = fma4(w[0], l0, acc); acc = fma4(w[1], h[j], acc); acc = fma4(w[2], r0, acc);
             acc = fma4(w[3], l1, acc); acc = fma4(w[4], h[j + 1], acc); acc = fma4(w[5], r1, acc);
             acc = fma4(w[6], l2, acc); acc = fma4(w[7], h[j + 2], acc); acc = fma4(w[8], r2, acc);
-            // the unfold's zero padding, as a mask on the packed record (a select on acc makes hipcc branch around the FMAs)
-            const unsigned in = (col_in && (unsigned)(gy + j) < (unsigned)Hp) ? 0xFFFFFFFFu : 0u;
             u32x2 hi, lo;
             split4(acc, hi, lo);
+#if RR_BORDER
+            if (wr_ok) dst[j * R3W] = u32x4{hi.x, hi.y, lo.x, lo.y};
+#else
+            // the unfold's zero padding, as a mask on the packed record (a select on acc makes hipcc branch around the FMAs)
+            const unsigned in = (col_in && (unsigned)(gy + j) < (unsigned)Hp) ? 0xFFFFFFFFu : 0u;
             if (wr_ok) dst[j * R3W] = u32x4{hi.x & in, hi.y & in, lo.x & in, lo.y & in};
+#endif
             l0 = l1; r0 = r1; l1 = l2; r1 = r2;
             __builtin_amdgcn_sched_barrier(0);      // row by row: hoisting the neighbour moves of all 13 rows would spill the columns
         }
+#if RR_BORDER
+        if (!rec_interior) {                        // the unfold's zero padding: records outside the image are zero
+            unsigned zz = 0u;
+            asm volatile("" : "+v"(zz));            // (defined here: hipcc otherwise keeps a zero vector in four registers across the whole tile loop)
+#pragma unroll 1
+            for (int j = 0; j < 11; ++j)
+                if (wr_ok && !(col_in && (unsigned)(gy + j) < (unsigned)Hp)) dst[j * R3W] = u32x4{zz, zz, zz, zz};
+        }
+#endif
     };
     if (RR_ON(4)) conv_records(p.wk, p.bk, KPLK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile's motion vectors have landed long ago
@@ -584,7 +619,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         for (int b = 0; b < 7; ++b) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                S[b][i] = __builtin_amdgcn_exp2f(fmaf(S[b][i], LOG2E, -ml));     // masked slots: exp2(-inf) = 0
+                if (RR_ON(11)) S[b][i] = __builtin_amdgcn_exp2f(fmaf(S[b][i], LOG2E, -ml));     // masked slots: exp2(-inf) = 0
                 z += S[b][i];
             }
             u32x2 hi, lo;
@@ -624,6 +659,12 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
         const int wave = __builtin_amdgcn_readfirstlane(t >> 6), pc = wave & 1, pr = wave >> 1;
         const int gyq = ty0 + 2 * pr + (q >> 3), gxq = tx0 + 8 * pc + (q & 7);       // this lane's query pixel
         const bool inq = gyq < Hp && gxq < Wp;
+        // byte offsets in 32 bits, once per tile (the entry point bounds both tensors below 2 GiB): per chunk / class only a uniform term is added
+        const unsigned pix = (unsigned)(gyq * Wp + gxq), plane = (unsigned)(Hp * Wp);
+        const unsigned p_off0 = p.p_layout == ARSEG_C8 ? (((unsigned)n * 8u + (unsigned)(g >> 1)) * plane + pix) * 32u + (unsigned)(g & 1) * 16u
+                                                       : ((unsigned)n * plane + pix) * (CH * 4u) + 16u * g;
+        const unsigned p_step = p.p_layout == ARSEG_C8 ? 2u * plane * 32u : 64u;      // chunk c: + c * p_step
+        const unsigned l_off0 = ((unsigned)n * (unsigned)p.n_cls * plane + pix) * 4u;
         f32x4 lg[NBA];
 #pragma unroll
         for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -634,39 +675,25 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             arseg_src_index(p.sy, min(gyq, Hp - 1), true, p.hp, y0, y1, ly);
             arseg_src_index(p.sx, min(gxq, Wp - 1), true, p.wp, x0, x1, lx);
             ly = fminf(fmaxf(ly, 0.f), 1.f); lx = fminf(fmaxf(lx, 0.f), 1.f);
-            const float *lrn = p.lr + (size_t)n * p.hp * p.wp * CH + 4 * g;
-            const float *a00p = lrn + (size_t)(y0 * p.wp + x0) * CH, *a01p = lrn + (size_t)(y0 * p.wp + x1) * CH;
-            const float *a10p = lrn + (size_t)(y1 * p.wp + x0) * CH, *a11p = lrn + (size_t)(y1 * p.wp + x1) * CH;
-            int vrec[7];
+            // 32-bit byte offsets into the lr tensor (buffer loads: the 64-bit pointers of four taps cost 8 registers in the phase with the
+            // highest register pressure of the kernel)
+            const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr), 0, (int)p.lr_bytes, 0x00020000);
+            const unsigned lrb = (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + 16u * g;
+            const unsigned o00 = lrb + (unsigned)(y0 * p.wp + x0) * (CH * 4u), o01 = lrb + (unsigned)(y0 * p.wp + x1) * (CH * 4u);
+            const unsigned o10 = lrb + (unsigned)(y1 * p.wp + x0) * (CH * 4u), o11 = lrb + (unsigned)(y1 * p.wp + x1) * (CH * 4u);
+            auto lr_tap = [&](unsigned o, int c) { return RR_ON(8) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, o, 64 * c, 0)) : f32x4{(float)o, 0.f, 0.f, 0.f}; };
+            // byte offset of the value record of (block b, this lane's key) in a channel-group plane: vbase + 384 b (+128 where bit b of
+            // vsel is set) -- see key_rec; one register pair instead of seven addresses
+            const int vk0 = 4 * g + (q >> 2);
+            const unsigned vbase = (unsigned)(2 * pr * R3W + 8 * pc + vk0) * 16u;
+            unsigned vsel = 0;
 #pragma unroll
-            for (int b = 0; b < 7; ++b) vrec[b] = key_rec(b, 4 * g + (q >> 2), 2 * pr * R3W + 8 * pc + 4 * g + (q >> 2)) * 16;
-            // the four taps of a chunk are requested one chunk ahead: their latency hides behind the 14 MFMAs of the current one
-            f32x4 a00 = *reinterpret_cast<const f32x4 *>(a00p), a01 = *reinterpret_cast<const f32x4 *>(a01p);
-            f32x4 a10 = *reinterpret_cast<const f32x4 *>(a10p), a11 = *reinterpret_cast<const f32x4 *>(a11p);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
-                if (c < 3) {
-                    a00 = *reinterpret_cast<const f32x4 *>(a00p + 16 * (c + 1)); a01 = *reinterpret_cast<const f32x4 *>(a01p + 16 * (c + 1));
-                    a10 = *reinterpret_cast<const f32x4 *>(a10p + 16 * (c + 1)); a11 = *reinterpret_cast<const f32x4 *>(a11p + 16 * (c + 1));
-                }
-                const unsigned char *va = reinterpret_cast<const unsigned char *>(BIGu + (4 * c + (q & 3)) * KPLV);
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int b = 0; b < 7; ++b) {
-                    const u32x2 vh = lds_tr16(va + vrec[b]), vl = lds_tr16(va + vrec[b] + 8);
-                    const h16x8 pb = __builtin_bit_cast(h16x8, P[b]);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
-                }
-                const f32x4 o = lrc + acc * inv;              // p[query][16c + 4g .. +3]
-                unsigned off;
-                if (p.p_layout == ARSEG_C8)
-                    off = (unsigned)(((((size_t)n * 8 + 2 * c + (g >> 1)) * Hp + gyq) * Wp + gxq) * 8 + (g & 1) * 4) * 4u;
-                else
-                    off = (unsigned)((((size_t)n * Hp + gyq) * Wp + gxq) * CH + 16 * c + 4 * g) * 4u;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? off : OOB, 0, 0);
-                if (NB > 0) {
+            for (int b = 0; b < 7; ++b) vsel |= (vk0 >= 14 - 2 * b ? 1u : 0u) << b;
+            auto vrec = [&](int b) { return vbase + 384u * b + (((vsel >> b) & 1u) << 7); };
+            auto epilogue = [&](int c, const f32x4 o) {       // o = p[query][16c + 4g .. +3]: store, then this chunk's share of the classifier
+                const unsigned off = p_off0 + (unsigned)c * p_step;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, (inq && RR_ON(9)) ? off : OOB, 0, 0);
+                if (NB > 0 && RR_ON(13)) {
                     u32x2 oh, ol;
                     split4(o, oh, ol);
                     const h16x8 o1 = pack8(oh, ol), o2 = pack8(ol, oh);
@@ -677,7 +704,65 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                         lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o2, lg[nb], 0, 0, 0);
                     }
                 }
+            };
+#if RR_PV2
+            // Block-major: the swapped weight operand (p_lo | p_hi) of a block is formed once (4 v_mov) and used by all four channel chunks --
+            // chunk-major order swapped the VALUE operand instead, 4 v_mov between every pair of dependent MFMAs (112 per tile).  Four
+            // independent accumulators, eight transpose reads in flight per block.  The residual taps of two chunks are requested ahead of
+            // the MFMAs, the others while the first epilogues run.
+            f32x4 tp[2][4];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { tp[c][0] = lr_tap(o00, c); tp[c][1] = lr_tap(o01, c); tp[c][2] = lr_tap(o10, c); tp[c][3] = lr_tap(o11, c); }
+            f32x4 acc[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const unsigned char *va0 = reinterpret_cast<const unsigned char *>(BIGu + (q & 3) * KPLV);
+#pragma unroll
+            for (int b = 0; b < 7; ++b) {
+                const h16x8 pb = __builtin_bit_cast(h16x8, P[b]), pbs = __builtin_bit_cast(h16x8, u32x4{P[b].z, P[b].w, P[b].x, P[b].y});
+                const unsigned vo = vrec(b);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned char *va = va0 + c * (4 * KPLV * 16);
+                    const h16x8 a = RR_ON(12) ? pack8(lds_tr16(va + vo), lds_tr16(va + vo + 8)) : pack8(u32x2{vo, vo}, u32x2{vo, (unsigned)c});
+                    if (RR_ON(10)) {
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, acc[c], 0, 0, 0);
+                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbs, acc[c], 0, 0, 0);
+                    } else {
+                        acc[c] += __builtin_bit_cast(f32x4, a) + __builtin_bit_cast(f32x4, pb);
+                    }
+                }
             }
+            RR_STAMP(14);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c == 2) RR_STAMP(0);
+                const f32x4 *t4 = tp[c & 1];
+                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * t4[0] + lx * t4[1]) + ly * ((1.f - lx) * t4[2] + lx * t4[3]);
+                if (c < 2) { tp[c][0] = lr_tap(o00, c + 2); tp[c][1] = lr_tap(o01, c + 2); tp[c][2] = lr_tap(o10, c + 2); tp[c][3] = lr_tap(o11, c + 2); }
+                epilogue(c, lrc + acc[c] * inv);
+            }
+#else
+            // the four taps of a chunk are requested one chunk ahead: their latency hides behind the 14 MFMAs of the current one
+            f32x4 a00 = lr_tap(o00, 0), a01 = lr_tap(o01, 0), a10 = lr_tap(o10, 0), a11 = lr_tap(o11, 0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
+                if (c < 3) {
+                    a00 = lr_tap(o00, c + 1); a01 = lr_tap(o01, c + 1); a10 = lr_tap(o10, c + 1); a11 = lr_tap(o11, c + 1);
+                }
+                const unsigned char *va = reinterpret_cast<const unsigned char *>(BIGu + (4 * c + (q & 3)) * KPLV);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int b = 0; b < 7; ++b) {
+                    const u32x2 vh = lds_tr16(va + vrec(b)), vl = lds_tr16(va + vrec(b) + 8);
+                    const h16x8 pb = __builtin_bit_cast(h16x8, P[b]);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
+                }
+                epilogue(c, lrc + acc * inv);
+            }
+#endif
         }
 
         // logits: lg[nb][i] = class 16nb + 4g + i of query q
@@ -710,8 +795,8 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int cls = nb * 16 + 4 * g + i;
-                    const unsigned off = (unsigned)(((((size_t)n * p.n_cls + cls) * Hp + gyq) * Wp + gxq) * sizeof(float));
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB, 0, 0);
+                    const unsigned off = l_off0 + (unsigned)cls * plane * 4u;
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls && RR_ON(14)) ? off : OOB, 0, 0);
                 }
         }
     }
@@ -756,7 +841,8 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
     ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
     if (C != CH || kH != 7 || kW != 7 || N > MAXN) return ARSEG_EUNSUPPORTED;
     if (p_layout != ARSEG_C8 && p_layout != ARSEG_NHWC) return ARSEG_EINVAL;
-    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31)) return ARSEG_EUNSUPPORTED;   // 32-bit buffer offsets
+    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)N * C * hp * wp * sizeof(float) >= (1ull << 31))
+        return ARSEG_EUNSUPPORTED;                                                             // 32-bit buffer offsets
     if ((size_t)Hp * Wp >= (1u << 30)) return ARSEG_EUNSUPPORTED;                              // tap index packing
     if (!ARSEG_ALIGNED16(lr) || !ARSEG_ALIGNED16(p_out) || !ARSEG_ALIGNED16(wq) || !ARSEG_ALIGNED16(wk) || !ARSEG_ALIGNED16(wv) ||
         !ARSEG_ALIGNED16(bq) || !ARSEG_ALIGNED16(bk) || !ARSEG_ALIGNED16(bv))
@@ -778,6 +864,7 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
     p.N = N; p.Hp = Hp; p.Wp = Wp; p.hp = hp; p.wp = wp; p.H = H; p.W = W; p.n_cls = head ? n_cls : 0; p.log_softmax = log_softmax;
     p.p_layout = p_layout; p.tiles_x = arseg_cdiv(Wp, TX); p.tiles_y = arseg_cdiv(Hp, TY);
     p.p_bytes = (unsigned)((size_t)N * C * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)N * n_cls * Hp * Wp * sizeof(float)) : 0u;
+    p.lr_bytes = (unsigned)((size_t)N * C * hp * wp * sizeof(float));
     p.sy = arseg_resize_scale(hp, Hp, true); p.sx = arseg_resize_scale(wp, Wp, true);
     p.dbg = nullptr;
 #ifdef RR_TIMING

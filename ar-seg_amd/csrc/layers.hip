@@ -626,6 +626,7 @@ __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *_
     __syncthreads();
     const int H = S * h, W = S * w, runs = w + 1;
     const long long total = (long long)N * H * runs;
+    const bool pred_vec = (reinterpret_cast<uintptr_t>(pred) & 15u) == 0;      // 16 / 8-byte label stores need an aligned base (rows are multiples of S)
     const float sc = arseg_resize_scale(h, H, false);          // = 1 / S exactly
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int j = (int)(idx % runs) - 1, oy = (int)((idx / runs) % H), n = (int)(idx / ((long long)runs * H));
@@ -651,7 +652,10 @@ __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *_
             for (int u = 0; u < 4; ++u) {
                 const float *bk = b + (size_t)min(k0 + u, n_cls - 1) * cs;
                 if (x1 > x0) {          // the two taps of a row are neighbours: one 8-byte load (the kernel is bound by the number of load instructions)
-                    const float2 a01 = *reinterpret_cast<const float2 *>(bk + o00), a11 = *reinterpret_cast<const float2 *>(bk + o10);
+                    // (a 4-byte aligned pair type: the address is odd in floats for every other run -- gfx950 global loads take any dword
+                    // address, and the reduced alignment makes that a defined access instead of a misaligned float2)
+                    typedef float f32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+                    const f32x2_a4 a01 = *reinterpret_cast<const f32x2_a4 *>(bk + o00), a11 = *reinterpret_cast<const f32x2_a4 *>(bk + o10);
                     t[u][0] = a01.x; t[u][1] = a01.y; t[u][2] = a11.x; t[u][3] = a11.y;
                 } else {
                     t[u][0] = bk[o00]; t[u][1] = bk[o01]; t[u][2] = bk[o10]; t[u][3] = bk[o11];
@@ -676,7 +680,7 @@ __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *_
         }
         const long long row = ((long long)n * H + oy) * W;
         const bool whole = xs >= 0 && xs + S <= W;              // interior run: S consecutive labels, S/2 * 4 bytes aligned (W = S w, xs = S j + S/2)
-        if (pred && whole && S >= 4) {                           // vector stores (scalar ones: 4 bytes per lane at a 4 S byte stride)
+        if (pred && whole && S >= 4 && pred_vec) {               // vector stores (scalar ones: 4 bytes per lane at a 4 S byte stride)
             if constexpr (S == 8) {
                 *reinterpret_cast<int4 *>(pred + row + xs) = int4{bi[0], bi[1], bi[2], bi[3]};
                 *reinterpret_cast<int4 *>(pred + row + xs + 4) = int4{bi[S > 4 ? 4 : 0], bi[S > 5 ? 5 : 0], bi[S > 6 ? 6 : 0], bi[S > 7 ? 7 : 0]};
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256) void argmax_confusion_up_kernel(const float *_
         for (int r = 0; r < S; ++r) {
             const int ox = xs + r;
             if (ox < 0 || ox >= W) continue;
-            if (pred && !(whole && S >= 4)) pred[row + ox] = bi[r];
+            if (pred && !(whole && S >= 4 && pred_vec)) pred[row + ox] = bi[r];
             if (hist && label) {
                 const long long lab = label[row + ox];
                 if (lab != ignore_label && lab >= 0 && lab < n_cls) atomicAdd(&lh[(int)lab * n_cls + bi[r]], 1u);

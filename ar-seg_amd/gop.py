@@ -74,8 +74,9 @@ class GopRunner:
         self._side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
     # ------------------------------------------------------------------ the exchange step
-    def _buffer(self, stacked: torch.Tensor) -> torch.Tensor:
-        shape = (self.world * stacked.shape[0],) + tuple(stacked.shape[1:])
+    def _buffer(self, stacked: torch.Tensor, replicas: Optional[int] = None) -> torch.Tensor:
+        """The lane's exchange buffer: `replicas` x stacked.shape[0] entries (all-gather: one slot per rank; broadcast: exactly one)."""
+        shape = ((self.world if replicas is None else replicas) * stacked.shape[0],) + tuple(stacked.shape[1:])
         key = self._lane if stacked.is_cuda else 0
         b = self._gather_bufs.get(key)
         if b is None or tuple(b.shape) != shape or b.dtype != stacked.dtype or b.device != stacked.device:
@@ -103,7 +104,7 @@ class GopRunner:
             else:
                 if like is None:
                     raise ValueError("single-GOP plan: ranks without the keyframe need `like` (shape / dtype / device of ref_p)")
-                buf = self._buffer(like.unsqueeze(0))[0]
+                buf = self._buffer(like.unsqueeze(0), replicas=1)[0]          # exactly ref_p's shape (not world x: 1 GB at world 8)
             dist.broadcast(buf, src=0, group=self.group)
             return [buf]
         per_rank = len(local_refs)
@@ -115,7 +116,8 @@ class GopRunner:
     # ------------------------------------------------------------------ schedules
     def run(self, keyframes, frames, mvs, like: Optional[torch.Tensor] = None):
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
-        if local_refs and local_refs[0].is_cuda:
+        probe = local_refs[0] if local_refs else (like if like is not None else next(iter(frames.values()), None))
+        if probe is not None and probe.is_cuda:          # also on ranks that own no keyframe (single-GOP plan): their buffer is per lane too
             self._lane = torch.cuda.current_stream().cuda_stream
         refs = self.exchange(local_refs, like)
         return {(g, d): self.nonkey_fn(refs[g], frames[(g, d)], mvs[(g, d)]) for (g, d) in self.plan}

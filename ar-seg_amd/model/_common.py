@@ -16,6 +16,7 @@ class HipModule(nn.Module):
     ``.cuda()`` / ``.to()``).
     """
 
+    SUPPORTS_16BIT = False            # whether forward() has a fp16 / bf16 storage path (set by the model classes that do)
     storage_dtype = torch.float32      # activation / weight storage of the forward: float32, or float16 / bfloat16 (set_storage)
 
     def __init__(self):
@@ -29,6 +30,8 @@ class HipModule(nn.Module):
         they are packed."""
         if dtype not in (torch.float32, torch.float16, torch.bfloat16):
             raise _lib.ArsegError(f"unsupported storage dtype {dtype}")
+        if dtype != torch.float32 and not self.SUPPORTS_16BIT:
+            raise _lib.ArsegError(f"{type(self).__name__} has no 16-bit storage path (only the BiSeNet family does); use torch.float32")
         self.storage_dtype = dtype
         return self
 

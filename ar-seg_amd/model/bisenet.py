@@ -219,6 +219,8 @@ class FeatureFusionModule(HipModule):
 
 
 class _BiSeBase(HipModule):
+    SUPPORTS_16BIT = True
+
     def _build(self, n_classes, backend, aux_mode):
         self.cp = ContextPath(backend=backend)
         self.sp = SpatialPath()

@@ -43,7 +43,8 @@ class profile:
         global _profile
         _profile = None
         torch.cuda.synchronize()
-        self.rows = [(name, flops, nbytes, s.elapsed_time(e)) for name, flops, nbytes, s, e in self.records]
+        self.rows = [(name, flops, nbytes, s.elapsed_time(e)) for name, flops, nbytes, s, e, _ in self.records]
+        self.tags = [tag for *_, tag in self.records]
         return False
 
     def summary(self):
@@ -56,6 +57,29 @@ class profile:
             r["bytes"] += nbytes
         return out
 
+    def layers(self):
+        """Per conv layer (one row per distinct shape + plan): every launch made on behalf of the layer (GEMM / patch kernel, Winograd
+        transforms, tap gather, materialised upsample), with the reference's direct-conv FLOP count of the layer."""
+        out = {}
+        for (name, flops, nbytes, ms), tag in zip(self.rows, self.tags):
+            if tag is None:
+                continue
+            r = out.setdefault(tag, {"calls": 0, "ms": 0.0, "kernels": {}})
+            r["ms"] += ms
+            r["kernels"][name] = r["kernels"].get(name, 0.0) + ms
+            r["calls"] += name == "conv2d"
+        rows = []
+        for (N, H, W, cin, cout, k, stride, dil, up2, plan, flops), r in out.items():
+            calls = max(r["calls"], 1)
+            rows.append({"N": N, "H": H, "W": W, "cin": cin, "cout": cout, "k": k, "stride": stride, "dil": dil, "up2": up2, "plan": plan,
+                         "calls": calls, "us_per_call": 1e3 * r["ms"] / calls, "gflop_per_call": flops / 1e9,
+                         "tflops": flops * calls / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else None,
+                         "us_by_kernel": {kk: 1e3 * v / calls for kk, v in r["kernels"].items()}})
+        return rows
+
+
+_layer_tag = None      # set by conv2d while it launches on behalf of one layer (profile.layers())
+
 
 def _launch(name, fn, *args, flops=0, nbytes=0):
     if _profile is None:
@@ -65,7 +89,7 @@ def _launch(name, fn, *args, flops=0, nbytes=0):
     s.record()
     check(fn(*args), name)
     e.record()
-    _profile.records.append((name, flops, nbytes, s, e))
+    _profile.records.append((name, flops, nbytes, s, e, _layer_tag))
 
 
 def _need_gpu(*tensors, dtype=torch.float32):
@@ -136,6 +160,11 @@ _workspaces = {}
 
 def workspace(nbytes: int, device) -> torch.Tensor:
     # one buffer per (device, stream): split-K partials of convs running concurrently on different streams must not alias
+    if torch.cuda.is_current_stream_capturing():
+        # Inside a HIP-graph capture the buffer comes from that graph's private pool and its address is baked into the graph: it belongs
+        # to the graph alone (the graph's pool keeps it alive), never to this cache -- a second graph captured on the same (singleton)
+        # capture stream, or eager code on a recycled stream id, would otherwise share split-K partial sums with it.
+        return torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     key = (torch.device(device).index or 0, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -591,6 +620,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         st = lib.arseg_conv2d_find(ctypes.byref(d), _ptr(xin), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws),
                                    nbytes, 3, ctypes.byref(cfg), ctypes.byref(sk), ctypes.byref(us), _stream())
         d.upsample2x, d.in_ld = 0, in_ld_hi
+        if st > 0:
+            check(st, "conv2d_find")                                # a HIP error is not "no plan": raise it
         return (cfg.value, sk.value) if st == _lib.ARSEG_OK else None
 
     if tile_cfg == 0 and split_k == 0 and _AUTOTUNE:
@@ -605,6 +636,12 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
             plan = find_native() if _NATIVE_FIND else None
             if plan is None:
                 plan = _tune_conv(launch, pc, N * Ho * Wo)
+            elif x_low is not None:
+                # with a fused upsample the library times only the patch-resident plans: also time the GEMM-tile plans on the materialised
+                # upsample and keep the faster
+                alt = _tune_conv(launch, pc, N * Ho * Wo, allow_patch=False)
+                if alt is not None and _time(lambda: launch(*alt, record=False)) < _time(lambda: launch(*plan, record=False)):
+                    plan = alt
             if plan is None:
                 # nothing could be launched.  The one shape-independent cause is the 2 GiB limit of the kernels' 32-bit buffer
                 # offsets on a large batch: split the batch (as creff does) instead of caching a plan that never ran.
@@ -639,14 +676,21 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 except _lib.ArsegError:
                     pass
             _conv_plans[key] = plan
-        if plan == "wino":
-            launch_wino()
-        elif plan == "tapsf":
-            _conv_up2_fused(x_low, pc, out)
-        elif plan == "taps":
-            launch_taps()
-        else:
-            launch(*plan)
+        global _layer_tag
+        outer_tag = _layer_tag          # the tap-decomposed route calls conv2d for its low-resolution GEMM: the outermost layer keeps the tag
+        if _profile is not None and outer_tag is None:
+            _layer_tag = (N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, x_low is not None, str(plan), flops)
+        try:
+            if plan == "wino":
+                launch_wino()
+            elif plan == "tapsf":
+                _conv_up2_fused(x_low, pc, out)
+            elif plan == "taps":
+                launch_taps()
+            else:
+                launch(*plan)
+        finally:
+            _layer_tag = outer_tag
     else:
         launch(tile_cfg, split_k)
     return out
@@ -810,11 +854,11 @@ def _conv_up2_fused(x_low, pc, out, record=True):
         check(lib.arseg_upconv3x3_fused_fwd(*args), "upconv3x3_fused")
 
 
-def _tune_conv(launch, pc, m):
+def _tune_conv(launch, pc, m, allow_patch=True):
     ktiles = (pc.R * pc.S * pc.cin_pad + 31) // 32
     best, best_t = (0, 0), float("inf")
-    patch_ok = (_math == _lib.MATH_F16X3 and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == pc.dil == 1 and pc.cin_pad % 32 == 0)
-    for cfg, sk in [(0, 0)] + _conv_candidates(ktiles, pc.cout, m, patch_ok):
+    patch_ok = allow_patch and (_math == _lib.MATH_F16X3 and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == pc.dil == 1 and pc.cin_pad % 32 == 0)
+    for cfg, sk in ([(0, 0)] if allow_patch else []) + _conv_candidates(ktiles, pc.cout, m, patch_ok):
         try:
             launch(cfg, sk, record=False)                          # warm (also sizes the workspace)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 
-GOP, SCALE = 12, 0.5
+GOP = 12
+MIN_TIMED_S = 1.0          # the timed region is extended (whole multiples of --steps) until it lasts at least this long
 # headline workload = BASELINE.json configs[1]; "psp2k" = the same network with the 512x1024 *non-key* reading of the metric
 # (SURVEY.md section 8 preamble); "bise" = configs[2] (BiSeNet-18, Cityscapes sizes) measured in fp32 --
 # the bf16 MFMA conv path that config names is not built yet, so it is an extra, not the headline.
@@ -91,6 +92,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=9)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the (slow) CPU oracle leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
+    ap.add_argument("--no-variants", action="store_true", help="skip the short runs of the other single-GPU BASELINE shapes (psp2k, bise_bf16, bise03_fp16)")
+    ap.add_argument("--variant-steps", type=int, default=9)
+    ap.add_argument("--conv-layers", metavar="FILE", help="also write the per-layer conv table (shape, plan, us, TFLOP/s, fraction of the MFMA peak) as JSON")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured HIP graph (N = 1 only)")
@@ -117,14 +121,38 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    result = run_config(args, args.config, args.steps, args.warmup, world, rank, dev, backend, full=True)
+    # ---- the other single-GPU BASELINE shapes, driver-timed in the same line (short runs)
+    if world == 1 and args.config == "psp" and not args.no_variants:
+        result["variants"] = {}
+        for name in ("psp2k", "bise_bf16", "bise03_fp16"):
+            try:
+                r = run_config(args, name, args.variant_steps, 3, world, rank, dev, backend, full=False)
+                result["variants"][name] = {
+                    "workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "dtype": r["dtype"], "steps": r["steps"],
+                    "ms_per_step": r["ms_per_step"],
+                    "creff_stage_frac_hbm": r.get("roofline", {}).get("frac"), "creff_stage_kernel": r.get("roofline", {}).get("kernel"),
+                    "conv_frac_mfma": r.get("roofline_conv", {}).get("frac"), "parity": r.get("parity")}
+            except Exception as exc:      # a variant must never take the headline line down with it
+                result["variants"][name] = {"error": repr(exc)}
+    if world > 1 and backend != "nccl":
+        result["rehearsal"] = f"backend {backend}, {world} ranks on {torch.cuda.device_count()} GPU(s): schedule check, not a measurement"
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
+    """One bench line for `config`.  full = the headline form (CPU baseline, CPU parity at every size, minimum timed duration);
+    otherwise a short variant run (throughput, roofline objects, label agreement against one oracle pass)."""
     from arseg_amd import _lib, evaluation as ev, ops, synth
     from arseg_amd.gop import GopRunner
 
     _lib.load()
     ops.set_conv_math(args.conv_math)
-    cfg = CONFIGS[args.config]
-    global SCALE
-    SCALE = cfg.get("scale", SCALE)
+    cfg = CONFIGS[config]
+    SCALE = cfg.get("scale", 0.5)
     H, W, N_CLS = cfg["H"], cfg["W"], cfg["n_cls"]
     mean, std = (synth.CAMVID_MEAN, synth.CAMVID_STD) if cfg["kind"] == "psp" else (synth.CITY_BISE_MEAN, synth.CITY_BISE_STD)
     hr, lr, sd_hr, sd_lr = build_nets(dev, cfg)
@@ -197,22 +225,33 @@ def main():
             i += 1
         return out
 
-    run_steps(args.warmup)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    outs = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
+    def timed_region(k):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = run_steps(k)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        return el, o
+
+    run_steps(warmup)
+    steps_requested = steps
+    elapsed, outs = timed_region(steps)
+    if full and elapsed < MIN_TIMED_S:
+        # the requested K steps are too short a window to trust (0.12 s at --steps 20): time a whole multiple of K that lasts
+        # >= 1 s instead; the multiple follows from the max-over-ranks time, so every rank runs the same number of steps
+        import math
+        steps = steps_requested * int(math.ceil(1.05 * MIN_TIMED_S / max(elapsed, 1e-6)))
+        elapsed, outs = timed_region(steps)
 
     nonkey_per_step = world * (GOP - 1)
     result = {
@@ -222,11 +261,11 @@ def main():
                    "bise03": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614",
                    "bise": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024",
                    "bise_bf16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 512x1024, bf16",
-                   "bise03_fp16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614, fp16"}[args.config],
-        "value": nonkey_per_step * args.steps / elapsed,
+                   "bise03_fp16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614, fp16"}[config],
+        "value": nonkey_per_step * steps / elapsed,
         "unit": "frames/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps,
+        "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "warmup": warmup, "timed_s": elapsed,
+        "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
         "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
@@ -235,7 +274,7 @@ def main():
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
-        "all_frames_per_s": world * GOP * args.steps / elapsed,
+        "all_frames_per_s": world * GOP * steps / elapsed,
     }
 
     # ---- per-kernel timing with HIP events on the launch stream (one extra, instrumented step)
@@ -266,10 +305,11 @@ def main():
         if storage != "f32":
             mfma_mult, peak = 1.0, PEAK_F16_MFMA_TFLOPS
         gemm_tf = tot_flops / (tot_ms * 1e-3) / 1e12
-        conv_traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r02_traffic.json")      # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this command (profiles/collect.sh)
-        traffic_db = {}
-        if os.path.exists(tfile) and args.config == "psp":
+        # rocprofv3 --pmc passes of this command (profiles/collect.sh -> profiles/traffic_<config>.json: FETCH_SIZE / WRITE_SIZE per launch and the
+        # SQ matrix-core counters per kernel family); absent for a config that has not been collected
+        conv_traffic, traffic_db = None, {}
+        tfile = os.path.join(ROOT, "profiles", f"traffic_{config}.json")
+        if os.path.exists(tfile):
             with open(tfile) as f:
                 traffic_db = json.load(f)
             conv_traffic = traffic_db.get("conv_all_tiles", {}).get("hbm_bytes_per_launch")
@@ -283,6 +323,7 @@ def main():
             "frac": ref_tf / peak if ref_tf else None,
             "frac_incl_winograd_transforms": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12 / peak if ref_flops else None,
             "mfma_issue_frac": mfma_mult * gemm_tf / peak,
+            "mfma_util_pmc": traffic_db.get("conv_all_tiles", {}).get("mfma_util"),
             "traffic": conv_traffic,
             "algorithmic_gflop_per_step": ref_flops / 1e9, "conv_ms_per_step": tot_ms, "winograd_transform_ms_per_step": wino_ms,
             "executed_gemm_tflops": gemm_tf,
@@ -290,14 +331,18 @@ def main():
             "note": "achieved = SURVEY 8d algorithmic FLOPs of one GOP step / summed conv-kernel time of that step (HIP events on the launch stream); "
                     "executed_gemm_tflops = the fp32 GEMM FLOPs the kernels execute (Winograd, the tap-decomposed upsample convs and the folded "
                     "pyramid execute fewer than the reference's direct convs); winograd_transform_ms_per_step also holds the tap-gather pass "
-                    "of the upsample convs; mfma_issue_frac counts each of those three times (the hi/lo emulation)",
+                    "of the upsample convs; mfma_issue_frac counts each of those three times (the hi/lo emulation); mfma_util_pmc = "
+                    "SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x GRBM_GUI_ACTIVE) over the conv kernels of the rocprofv3 --pmc pass "
+                    f"(profiles/traffic_{config}.json)",
         }
         # ---- dominant kernel of the step (rocprofv3 kernel stats, profiles/r02_*_kernel_stats.csv): the warp + CReFF stage, HBM-bound by the
         # SURVEY 8d accounting.  B = ref_p read + lr read + p write + int16x2 MV read + logits write, per non-keyframe; one launch = this rank's
         # batch of non-keyframes.
         C, fd = cfg["C"], cfg["feat_div"]
         Hp, Wp = H // fd, W // fd
-        logit_px = Hp * Wp if cfg["kind"] == "semseg" else H * W              # pspnet_semseg phase 2 returns logits at feature resolution
+        # logits as the timed kernels write them: PSPNet at frame resolution; pspnet_semseg and BiSeNet (fused x8 upsample + argmax tail: the
+        # [19,H,W] logits are never written) at feature resolution -- VERDICT r2: the r02 lines counted 159 MB per frame that never moved
+        logit_px = H * W if cfg["kind"] == "psp" else Hp * Wp
         e_in = 2 if storage != "f32" else 4                                 # element size of ref_p / lr; p and the logits leave the CReFF kernel in fp32
         hp_, wp_ = int(H * SCALE) // fd if cfg["kind"] != "psp" else H // 2, int(W * SCALE) // fd if cfg["kind"] != "psp" else W // 2
         stage_bytes = e_in * C * Hp * Wp + e_in * C * max(hp_, 1) * max(wp_, 1) + 4 * C * Hp * Wp + 4 * H * W + 4 * N_CLS * logit_px
@@ -319,11 +364,25 @@ def main():
             "algorithmic_bytes_per_unit": stage_bytes, "units_per_launch": nfr, "avg_launch_ms": launch_ms,
             "warp_ms_per_frame": wrp["ms"] / nb, "creff_ms_per_frame": cre["ms"] / nb,
             "kernel_gflops": cre["flops"] / (cre["ms"] * 1e-3) / 1e9,
+            "mfma_util_pmc": kt.get("mfma_util") if kt else None,
             "note": "achieved = SURVEY 8d algorithmic bytes per non-keyframe x frames per launch / the kernel's average launch duration (HIP events "
-                    "on the launch stream); traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the rocprofv3 --pmc passes (profiles/r02_traffic.json)",
+                    "on the launch stream); traffic = (2 x FETCH_SIZE + WRITE_SIZE) per launch from the rocprofv3 --pmc passes "
+                    f"(profiles/traffic_{config}.json)",
         }
         result["per_frame_ms"] = {"lr_frame_by_op": {k: v["ms"] / nb for k, v in sorted(nk.items())},
                                   "hr_keyframe_by_op": {k: v["ms"] for k, v in sorted(ky.items())}}
+        if args.conv_layers and full:
+            def table(rows, div):
+                for r in rows:
+                    r["calls"] = r["calls"] / div
+                    r["frac_of_peak"] = r["tflops"] / peak if r["tflops"] else None
+                return sorted(rows, key=lambda r: -r["us_per_call"] * r["calls"])
+            with open(args.conv_layers, "w") as f:
+                json.dump({"config": config, "conv_math": args.conv_math, "peak_tflops": peak,
+                           "note": "one row per conv layer shape + plan: us_per_call = every launch made for the layer (GEMM / patch kernel, Winograd "
+                                   "transforms, tap gather) by HIP events; tflops = the reference's direct-conv FLOPs of the layer / that time; "
+                                   "lr = the 11-frame LR batch of one GOP step, hr = the keyframe's HR forward",
+                           "lr": table(prof_nk.layers(), 3), "hr": table(prof_key.layers(), 1)}, f, indent=1)
 
     # ---- CPU baseline (rank 0, N=1 only): the oracle (a port) on one non-keyframe of the same clip; also the parity check
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -370,21 +429,35 @@ def main():
                 keep["r"] = cpu_ref.alter_res_step(cfg["kind"], sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), SCALE, ref_p=ref_cpu)
 
             reps = (1, 3) if cfg["H"] * cfg["W"] > 512 * 1024 else (2, 5)         # the 1024x2048 extras: a shorter sample
+            if not full:
+                reps = (0, 1)                                                     # a variant line: one oracle pass for the parity figures
             cpu_s, samples = timed(one_frame, *reps)
             o_out, o_p, _, _ = keep["r"]
+            cpu_all = None
+            if full and host_cores > ncores:
+                # SURVEY 8d asks for os.cpu_count() threads; the oracle's strip-wise ops do not scale that far, so both are reported
+                torch.set_num_threads(host_cores)
+                all_s, all_samples = timed(one_frame, 1, 2)
+                cpu_all = {"value": 1.0 / all_s, "unit": "frames/s", "cores": torch.get_num_threads(), "seconds": all_s, "seconds_all": all_samples,
+                           "sample": "the same sample at os.cpu_count() threads; 1 warm-up + 2 timed runs, median"}
+                torch.set_num_threads(ncores)
         if fused_tail:          # the timed step ends in the fused argmax; the logits for the parity figure come from one extra untimed pass
             with torch.no_grad():
                 pred0 = outs[0:1].cpu().long()
                 outs = ev.alter_res_batch_fast(lr, [key_fn(keyframes[g0])], frames_b[0:1], mvs_b[0:1], SCALE)[0]
         got = outs[0:1].cpu()                                              # plan[0] is the first frame of the batch
         ref_gpu = ops.as_nchw(key_fn(keyframes[g0]).unsqueeze(0)).cpu()
+        if cpu_all is not None:
+            result["cpu_baseline_all_cores"] = dict(cpu_all, kind="port", host_cores=host_cores)
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "host_cores": host_cores, "cpu_model": cpu_model(),
                                   "sample": f"1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same {H}x{W} clip with "
                                             f"the PyTorch-CPU oracle, keyframe feature precomputed outside the sample; {reps[0]} warm-up + {reps[1]} "
                                             "timed runs, median",
                                   "seconds": cpu_s, "seconds_all": samples}
-        if cfg["kind"] == "psp":
+        if not full:
+            del result["cpu_baseline"]          # (a single untimed-quality pass: not a baseline)
+        if cfg["kind"] == "psp" and full:
             # BASELINE configs[0]: PSPNet-18 HR branch on one 720x960 CamVid-sized frame, PyTorch-CPU forward, no CReFF (evaluation.py --mode 1 0 0)
             frame_c1 = torch.from_numpy(synth.make_clip(0, 720, 960, gop=1, mean=mean, std=std)["frames"][0:1])
             with torch.no_grad():
@@ -399,12 +472,7 @@ def main():
                             "tolerance": 1e-3}
         if fused_tail:
             result["parity"]["fused_tail_label_agreement"] = float((pred0 == o_out.argmax(1)).float().mean())
-    if world > 1 and backend != "nccl":
-        result["rehearsal"] = f"backend {backend}, {world} ranks on {torch.cuda.device_count()} GPU(s): schedule check, not a measurement"
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
-        dist.destroy_process_group()
+    return result
 
 
 if __name__ == "__main__":

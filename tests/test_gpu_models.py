@@ -171,8 +171,16 @@ def test_eval_alter_res_golden(dev, golden, manifest, kind):
         pred, hist = ops.argmax_confusion(out_f, label.to(dev), label.shape[-2], label.shape[-1])
     assert maxdiff(out_f, g["out"]) <= TOL
     assert maxdiff(ops.from_c8(p_c8, _lib.NCHW)[..., ::2, ::2], g["p_s2"]) <= TOL
-    assert (pred.cpu().long().numpy() != g["preds"]).mean() <= 2e-3
-    assert float((hist.cpu().float() - t(g["hist"])).abs().sum()) <= 8
+    # index outputs: the labels are EXACTLY the reference's wherever the reference's top-2 margin exceeds twice the
+    # measured logit error -- no argmax can flip there; the remaining near-ties are counted, bounded and the only source of histogram moves
+    err = maxdiff(out_f, g["out"])
+    top2g = torch.from_numpy(np.asarray(g["out"])).topk(2, dim=1).values
+    safe = ((top2g[:, 0] - top2g[:, 1]) > 2 * err + 1e-7).numpy()
+    n_tie = int((~safe).sum())
+    print(f"\n[g7 {kind}] logit err {err:.2e}; labels compared exactly on {int(safe.sum())} of {safe.size} pixels, {n_tie} near-ties excluded")
+    assert np.array_equal(pred.cpu().long().numpy()[safe], g["preds"][safe])
+    assert n_tie <= 2e-3 * safe.size
+    assert float((hist.cpu().float() - t(g["hist"])).abs().sum()) <= 2 * n_tie
     # fused evaluator tail (BiSeNet: head -> x8 upsample -> argmax without the full-resolution logits) against the reference's
     # preds / confusion matrix: labels may differ only where the reference's top two classes are within 1e-4 of each other
     with torch.no_grad():
@@ -239,6 +247,11 @@ def test_eval_alter_res_undamped_golden(dev, golden, manifest, kind):
     # CReFF stage alone sits 1.5e-5 of the magnitude away from fp64 (printed above)
     assert e_p <= 4e-4 * a_p and e_out <= 4e-4 * a_o
     assert agree >= 0.998
+    # index outputs: exact on every pixel whose reference top-2 margin exceeds twice the measured logit error
+    top2g = torch.from_numpy(np.asarray(g["out"])).topk(2, dim=1).values
+    safe = ((top2g[:, 0] - top2g[:, 1]) > 2 * e_out + 1e-7).numpy()
+    print(f"[undamped {kind}] labels compared exactly on {int(safe.sum())} of {safe.size} pixels ({int((~safe).sum())} within 2 x the logit error of a tie)")
+    assert np.array_equal(pred.cpu().long().numpy()[safe], g["preds"][safe])
 
 
 def test_modules_fail_loudly_off_gpu(manifest):
