@@ -30,7 +30,7 @@ class ConvDesc(Structure):
                 ("R", c_int), ("S", c_int), ("stride", c_int), ("pad", c_int), ("dil", c_int),
                 ("act", c_int), ("prelu_slope", c_float), ("tile_cfg", c_int), ("split_k", c_int),
                 ("batch", c_int), ("in_batch_stride", c_int64), ("w_batch_stride", c_int64), ("out_batch_stride", c_int64),
-                ("math", c_int), ("upsample2x", c_int)]
+                ("math", c_int), ("upsample2x", c_int), ("range_flag", c_void_p), ("range_limit", c_float)]
 
 
 _P = c_void_p  # device or host pointer passed as integer
@@ -84,6 +84,7 @@ PROTOTYPES = {
     "arseg_warp_mvq16_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_adaptive_avgpool_blockrow_fwd": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_psp_prior_sum_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_global_reduce_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_resize_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),

@@ -58,6 +58,8 @@ struct ConvParams {
     int tiles_m, tiles_n;
     int inv_S;                       // 65536/S + 1: r = (rs*inv_S) >> 16 without a division
     int up2;                         // patch kernel: `in` is the low-resolution tensor [N, H/2, W/2, in_ld], convolved after a x2 bilinear upsample
+    unsigned *range_flag;            // F16X3: sticky status word (or null): bit 0 is set when an A operand exceeds range_limit in magnitude
+    float range_limit;
     unsigned in_bytes, w_bytes;      // extents for the buffer descriptors
     unsigned out_bytes, res_bytes;   // extent of one problem's output / residual if below 2 GiB (branch-free epilogue through buffer stores), else 0
     long long in_bs, w_bs, out_bs;   // batched GEMM mode (blockIdx.y = batch index): element strides between problems
@@ -77,6 +79,16 @@ __device__ __forceinline__ void split_f16x3(const f32x4 v, uint2 &hi, uint2 &lo)
     unsigned h01, h23, l01, l23;
     arseg_split_f16(v, h01, h23, l01, l23);
     hi = uint2{h01, h23}; lo = uint2{l01, l23};
+}
+
+// Operand range watch of the split-fp16 back end (arseg_conv_desc.range_flag): the running maximum |a| of the activations a thread splits.
+// Only the workgroups of output-channel tile 0 watch, so every activation is examined once per conv (per tap), not once per N tile; inf / NaN operands are not flagged (they propagate into the output by themselves), the silent case -- finite values the hi/lo
+// pair can only clamp -- is.
+__device__ __forceinline__ void range_watch(float &vmax, const f32x4 v) {
+    vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+}
+__device__ __forceinline__ void range_report(const ConvParams &p, bool watch, float vmax) {
+    if (watch && vmax > p.range_limit) atomicOr(p.range_flag, 1u);
 }
 
 // Branch-free epilogue of one accumulator element: scale, bias, residual, activation, store.  The bounds tests become out-of-range
@@ -122,6 +134,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;   // n fastest: neighbours share A rows
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool watch = MATH == ARSEG_MATH_F16X3 && p.range_flag != nullptr && tile_n == 0;      // (every split-K slice: each covers its own part of K)
+    float vmax = 0.f;
     float *__restrict__ gout = p.out + (size_t)blockIdx.y * p.out_bs;
     // operands through buffer descriptors: a load whose offset is out of range returns zeros, which is how image padding,
     // tile tails and K padding are produced without branches
@@ -198,6 +212,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
             if (MATH == ARSEG_MATH_F16X3) {             // per 32-k tile: halves [0,32) hi, [32,64) lo
                 uint2 hi, lo;
                 split_f16x3(__builtin_bit_cast(f32x4, rg.a[i]), hi, lo);
+                if (watch) range_watch(vmax, __builtin_bit_cast(f32x4, rg.a[i]));
                 *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + (chunk & 7) * 2) = hi;
                 *reinterpret_cast<uint2 *>(row + (chunk >> 3) * 32 + 16 + (chunk & 7) * 2) = lo;
             } else if (MATH == ARSEG_MATH_F16) {        // plain fp16 operands (round to nearest), the lo halves stay unused
@@ -344,6 +359,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
 
     if (DUAL) acc[0][0] += acc2[0];
 
+    range_report(p, watch, vmax);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.nsplit == 1 && p.out_bytes) {
         constexpr unsigned OOBS = 0x80000000u;
@@ -436,6 +452,8 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
     const int img = tile_m / (tiles_x * tiles_y), trem = tile_m - img * (tiles_x * tiles_y);
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem - (trem / tiles_x) * tiles_x) * TW, n0 = tile_n * BN;
+    const bool watch = p.range_flag != nullptr && tile_n == 0;
+    float vmax = 0.f;
 
     const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.in), 0, (int)p.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.w), 0, (int)p.w_bytes, 0x00020000);
@@ -501,6 +519,7 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
     auto put_px = [&](int px, int piece, const f32x4 v) {
         uint2 hi, lo;
         split_f16x3(v, hi, lo);
+        if (watch) range_watch(vmax, v);
         unsigned char *row = Ps + px * ROWB + piece * 8;
         *reinterpret_cast<uint2 *>(row) = hi;
         *reinterpret_cast<uint2 *>(row + 64) = lo;
@@ -623,6 +642,7 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_ke
         if (s_ + 1 < nsteps) step(s_ + 1, r0, r1);
     }
 
+    range_report(p, watch, vmax);
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.out_bytes) {
         constexpr unsigned OOBS = 0x80000000u;
@@ -886,6 +906,9 @@ extern "C" int arseg_conv2d_fwd(const arseg_conv_desc *d, const float *in, const
     if (d->batch > 1 && (residual || d->batch > 65535 || (d->in_batch_stride & 3) || (d->w_batch_stride & 3))) return ARSEG_EINVAL;
     hipStream_t hs = arseg_stream(stream);
     p.up2 = d->upsample2x ? 1 : 0;
+    p.range_flag = d->math == ARSEG_MATH_F16X3 ? reinterpret_cast<unsigned *>(d->range_flag) : nullptr;
+    p.range_limit = d->range_limit > 0.0f ? d->range_limit : 65504.0f;
+    if (p.range_flag && (reinterpret_cast<uintptr_t>(p.range_flag) & 3)) return ARSEG_EINVAL;
     if (pl.patch_tw) {
         p.in_bytes = d->upsample2x ? (unsigned)((((long long)d->N * (d->H >> 1) * (d->W >> 1) - 1) * d->in_ld + d->Cin) * 4)
                                    : (unsigned)((((long long)d->N * d->H * d->W - 1) * d->in_ld + d->Cin) * 4);

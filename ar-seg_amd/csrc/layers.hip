@@ -44,7 +44,8 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
 // global mean / max), which are pure streaming reads.
 template <bool IS_MAX, int PL = 64>      // PL pixel lanes x 4 channel vectors: 256 threads, or 1024 for launches with few blocks
 __global__ __launch_bounds__(4 * PL) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
-                                                               int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow) {
+                                                               int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow,
+                                                               int zb_n = 0, int zb_self = 0) {
     __shared__ f32x4 red[PL][5];
     const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
     const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
@@ -77,7 +78,12 @@ __global__ __launch_bounds__(4 * PL) void window_reduce_kernel(const float *__re
     if (pl == 0 && c < C) {
         f32x4 t = red[0][cv];
         if (!IS_MAX) t = t / (float)cnt;
-        *reinterpret_cast<f32x4 *>(out + (size_t)n * out_n_stride + (size_t)bin * out_ld + c) = t;
+        float *o = out + (size_t)n * out_n_stride + (size_t)bin * out_ld + c;
+        *reinterpret_cast<f32x4 *>(o) = t;
+        // block-row mode (folded PSP pyramid): the row holds zb_n column blocks of C channels, this level owns block zb_self (`out` points at
+        // its first column) -- the same channels of the sibling blocks are zero, written here instead of by a fill launch
+        for (int j = 0; j < zb_n; ++j)
+            if (j != zb_self) *reinterpret_cast<f32x4 *>(o + (j - zb_self) * C) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -730,6 +736,25 @@ extern "C" int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out
         hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
     else
         hipLaunchKernelGGL((window_reduce_kernel<false, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, out, out_ld, out_n_stride, H, W, C, oh, ow);
+    return arseg_launch_status();
+}
+
+// adaptive average pooling into one column block of a block-structured matrix [N][rows][n_blocks * C] (the folded PSP pyramid,
+// model/pspnet.py:14-31): level `block` writes its pooled map into columns [block*C, (block+1)*C) of its rows and zeros into the same rows of
+// the other blocks.  `out` = first row of the level in image 0 (column 0 of the matrix); out_n_stride = elements between images.
+extern "C" int arseg_adaptive_avgpool_blockrow_fwd(const float *in, int in_ld, float *out, long long out_n_stride, int N, int H, int W, int C,
+                                                   int oh, int ow, int n_blocks, int block, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    ARSEG_CHECK_POS(oh); ARSEG_CHECK_POS(ow); ARSEG_CHECK_POS(n_blocks);
+    if (block < 0 || block >= n_blocks) return ARSEG_EINVAL;
+    const int out_ld = n_blocks * C;
+    if ((C & 3) || (in_ld & 3) || in_ld < C || (out_n_stride & 3) || out_n_stride < (long long)oh * ow * out_ld || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    const dim3 grid(oh * ow, arseg_cdiv(C, 16), N);
+    float *o = out + (size_t)block * C;
+    if ((long long)grid.x * grid.y * grid.z < 256)
+        hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
+    else
+        hipLaunchKernelGGL((window_reduce_kernel<false, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
     return arseg_launch_status();
 }
 

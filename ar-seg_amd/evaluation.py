@@ -55,6 +55,9 @@ class EvalConstRes(object):
         self.scale = scale
 
     def __call__(self, net, dl, n_classes):
+        return _range_safe(lambda: self._run(net, dl, n_classes), dl)
+
+    def _run(self, net, dl, n_classes):
         hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
         for imgs, label, *_ in dl:
             label = label.cuda()
@@ -66,6 +69,24 @@ class EvalConstRes(object):
             logits = net(imgs)[0]
             _, hist = ops.argmax_confusion(logits, label, label.shape[-2], label.shape[-1], hist, self.ignore_label, want_pred=False)
         return _miou(hist, n_classes)
+
+
+def _range_safe(run, dl):
+    """Runs an evaluation pass; if the split-fp16 convs met an activation outside their operand range (the sticky device word of
+    ops.range_tripped -- read once, after the pass, which ends in a host read anyway), the pass is repeated on the fp32 matrix-core back
+    end.  A one-shot iterator cannot be replayed: that raises instead of returning a possibly clamped result."""
+    ops.range_tripped()                      # clear what earlier launches left
+    result = run()
+    if not ops.range_tripped():
+        return result
+    if iter(dl) is dl:
+        raise _lib.ArsegError("an activation left the split-fp16 operand range (|x| > 65504) and the data iterator cannot be replayed: "
+                              "evaluate with ops.set_conv_math('f32')")
+    prev = ops.set_conv_math("f32")
+    try:
+        return run()
+    finally:
+        ops.set_conv_math(prev)
 
 
 def _resize_frames(imgs, h, w):
@@ -97,6 +118,9 @@ class EvalAlterRes(object):
         self.hr_forwards = 0
 
     def __call__(self, highres_net, net, dl, n_classes):
+        return _range_safe(lambda: self._run(highres_net, net, dl, n_classes), dl)
+
+    def _run(self, highres_net, net, dl, n_classes):
         hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
         lr_net = _unwrap(net)
         last_ref, last_p = None, None

@@ -51,14 +51,10 @@ class PSPModule(HipModule):
     def forward_nhwc(self, feats):
         pk = self.packed()
         N, h, w, C = feats.shape
-        n = len(self.sizes)
         rows = sum(s * s for s in self.sizes)
-        # block-structured matrix: the rows of level i hold its pooled map in columns [i*C, (i+1)*C), zeros elsewhere
-        pooled = torch.zeros((N, rows, 1, n * C), dtype=torch.float32, device=feats.device)
-        off = 0
-        for i, s in enumerate(self.sizes):
-            ops.adaptive_avgpool(feats, s, s, out=pooled[0, off, 0, i * C:], out_ld=n * C, out_n_stride=rows * n * C)
-            off += s * s
+        # block-structured matrix: the rows of level i hold its pooled map in columns [i*C, (i+1)*C), zeros elsewhere (written by the
+        # pooling launches themselves: a torch.zeros here was a fill launch per forward, 2.4 % of the traced GPU time in round 2)
+        pooled = ops.psp_pool_matrix(feats, self.sizes)
         t = ops.conv2d(pooled, pk["prior"])                                   # [N, rows, 1, 1024]: all levels, one launch
         prior = ops.psp_prior_sum(t.reshape(N, rows, -1), self.sizes, h, w)   # sum_s upsample(t_s), F.upsample default mode
         return ops.conv2d(feats, pk["feat"], residual=prior)                  # + W_f f + b, ReLU

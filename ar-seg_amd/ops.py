@@ -469,13 +469,50 @@ def set_conv_math(name: str) -> str:
     prev = [k for k, v in _MATH_NAMES.items() if v == _math][0]
     _math = _MATH_NAMES[name]
     return prev
-# Optional operand-range guard of the split-fp16 back end (include/arseg_hip.h, ARSEG_MATH_F16X3: |x| <= 131008 for the direct plans,
-# ~2e4 in the worst case for the Winograd route): ARSEG_CONV_RANGE_GUARD=1 checks the amax of every conv input (one reduction + a host
-# sync per conv: a validation mode, not for the steady state -- and not capturable into a HIP graph) and evaluates a layer whose
-# input leaves the range (or holds NaN / Inf) with the fp32 MFMA back end instead.  The networks of this path normalise after every
-# conv (BatchNorm), so their activations stay orders of magnitude inside the range; the guard is for foreign inputs.
-_RANGE_GUARD = os.environ.get("ARSEG_CONV_RANGE_GUARD", "0") == "1"
+# Operand-range safety of the split-fp16 back end (include/arseg_hip.h, ARSEG_MATH_F16X3: the hi/lo pair carries 22 bits up to |x| = 65504
+# and clamps beyond 131008; the Winograd route multiplies TRANSFORMED activations, ~10x the input).
+#   * default ("device"): every f16x3 conv gets a sticky device word (arseg_conv_desc.range_flag); the kernels set it when an activation
+#     they multiply exceeds 65504 -- no host synchronisation, capturable.  The host reads the word once per batch of launches with
+#     ops.range_tripped() (one sync) and repeats the batch under ops.set_conv_math("f32") -- evaluation.Eval*Res do, bench.py reports it.
+#   * ARSEG_CONV_RANGE_GUARD=host: the round-2 validation mode -- amax of every conv input with one host sync per conv, the layer is
+#     evaluated with the fp32 MFMA back end at once (not capturable).   * ARSEG_CONV_RANGE_GUARD=0: off.
+_RANGE_MODE = {"1": "host", "host": "host", "0": "off", "off": "off"}.get(os.environ.get("ARSEG_CONV_RANGE_GUARD", "device"), "device")
+_RANGE_GUARD = _RANGE_MODE == "host"
 _RANGE_LIMIT = 2.0e4
+_range_words = {}
+
+
+def _range_word(device):
+    """The device's sticky status word (allocated outside any graph capture; None while capturing before the first eager conv)."""
+    idx = torch.device(device).index or 0
+    w = _range_words.get(idx)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        w = _range_words[idx] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+def _arm_range_watch(d, device):
+    if _RANGE_MODE == "device" and d.math == _lib.MATH_F16X3:
+        w = _range_word(device)
+        if w is not None:
+            d.range_flag, d.range_limit = w.data_ptr(), 65504.0
+
+
+def range_tripped(device=None, reset: bool = True) -> bool:
+    """True if an f16x3 conv launched since the last reset multiplied an activation beyond the split-fp16 range (its result may be
+    clamped): repeat those launches with set_conv_math("f32").  One device -> host read (synchronises the current stream)."""
+    idx = torch.device(device).index or 0 if device is not None else torch.cuda.current_device()
+    w = _range_words.get(idx)
+    if w is None:
+        return False
+    hit = bool(int(w.item()) & 1)
+    if hit and reset:
+        w.zero_()
+    return hit
+
+
 _PLAN_FILE = os.environ.get("ARSEG_CONV_PLAN_FILE")       # optional: persist tuned plans (skips the trial launches next time)
 
 
@@ -563,6 +600,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     d.act, d.prelu_slope = pc.act, pc.slope
     d.tile_cfg, d.split_k = tile_cfg, split_k
     d.math = math = _math
+    _arm_range_watch(d, dev)
     w_dev, scale_dev = (pc.w_h3, pc.scale_h3) if math != _lib.MATH_F32 else (pc.w, pc.scale)
     d.out_ld, d.res_ld = pc.cout, pc.cout     # provisional, for the shape query
     lib = _lib.load()
@@ -793,6 +831,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     d.act, d.prelu_slope = _lib.ACT_NONE, 0.0
     d.batch, d.in_batch_stride, d.w_batch_stride, d.out_batch_stride = 36, T * Cin, Cout * Cin, T * Cout
     d.math = math = _math
+    _arm_range_watch(d, x.device)          # the batched GEMM watches the transformed activations it multiplies
     u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math != _lib.MATH_F32 else (pc.wino_u, pc.scale)
     key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
     plan = _conv_plans.get(key)
@@ -904,6 +943,21 @@ def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int, out: Optional[torch.Tens
         out = torch.empty((N, oh, ow, C), dtype=torch.float32, device=x.device)
     _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), out_ld, out_n_stride, N, H, W, C,
             oh, ow, _stream())
+    return out
+
+
+def psp_pool_matrix(x: torch.Tensor, sizes) -> torch.Tensor:
+    """The folded pyramid's block-structured pooled matrix [N, sum(s^2), 1, len(sizes)*C]: level i's adaptive average pool in columns
+    [i*C, (i+1)*C) of its s_i^2 rows, zeros elsewhere -- written entirely by the pooling launches (no fill)."""
+    _need_gpu(x)
+    N, H, W, C = x.shape
+    n, rows = len(sizes), sum(s * s for s in sizes)
+    out = torch.empty((N, rows, 1, n * C), dtype=torch.float32, device=x.device)
+    off = 0
+    for i, s in enumerate(sizes):
+        _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_blockrow_fwd, _ptr(x), _nhwc_ld(x), _ptr(out[0, off]), rows * n * C,
+                N, H, W, C, s, s, n, i, _stream())
+        off += s * s
     return out
 
 

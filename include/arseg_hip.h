@@ -144,7 +144,9 @@ int arseg_from_c8_fwd(const float *in, float *out, int layout, int out_ld, int N
 
 /* ---------------------------------------------------------------------------------------------
  * conv2d (+ folded BatchNorm / bias, + residual add, + activation) as an implicit GEMM on the
- * fp32 MFMA (v_mfma_f32_32x32x2_f32).  Replaces every nn.Conv2d/BatchNorm2d/ReLU/PReLU stack of
+ * matrix cores: desc.math selects the back end -- ARSEG_MATH_F16X3 (default of the Python side: every fp32 operand split
+ * into hi + lo fp16, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation; operand range below) or ARSEG_MATH_F32
+ * (v_mfma_f32_32x32x2_f32).  Replaces every nn.Conv2d/BatchNorm2d/ReLU/PReLU stack of
  * model/extractors.py:35-66,108-158, model/pspnet.py:14-46 and model/bisenet.py:31-60,162-399.
  *   out[n,oy,ox,co] = act( scale[co] * sum_{r,s,ci} in[n, oy*stride-pad+r*dil, ox*stride-pad+s*dil, ci]
  *                                        * w[co][(r*S+s)*Cin+ci]  + bias[co] + residual[n,oy,ox,co] )
@@ -176,6 +178,13 @@ typedef struct arseg_conv_desc {
                           the conv's input size, both even, dil == 1.  Patch-resident plans only (tile_cfg 13..16; the 16-bit conv
                           ignores it); ARSEG_EUNSUPPORTED otherwise -- the Winograd route has its own fused form
                           (arseg_wino43_input_fwd upsample2x). */
+    void *range_flag;  /* ARSEG_MATH_F16X3 only, may be NULL: a caller-owned, 4-byte aligned device word.  Bit 0 is set (atomic OR, never
+                          cleared by the library) when an activation this conv multiplies exceeds range_limit in magnitude, i.e. when
+                          the hi/lo fp16 pair starts to lose bits (65504) or clamps (131008): the caller reads the word once per
+                          batch of launches and repeats the batch with ARSEG_MATH_F32 if it is set.  The Winograd route passes the
+                          same word to its batched GEMM, which watches the TRANSFORMED activations it actually multiplies.  No host
+                          synchronisation, one v_max3 per 2 activations in 1 / (Cout / tile) of the workgroups. */
+    float range_limit; /* <= 0: 65504 */
 } arseg_conv_desc;
 
 /* ARSEG_MATH_F32:   v_mfma_f32_32x32x2_f32 on the fp32 operands; w_packed from arseg_pack_conv_weight_host.
@@ -270,6 +279,11 @@ int arseg_maxpool3x3s2_fwd(const float *in, float *out, int N, int H, int W, int
  * so several pyramid levels can be pooled straight into one block-structured matrix. */
 int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int out_ld, long long out_n_stride, int N, int H, int W,
                                int C, int oh, int ow, arseg_stream_t stream);
+/* The same into one column block of a block-structured matrix [N][rows][n_blocks*C] (the folded PSP pyramid, model/pspnet.py:14-31):
+ * level `block` writes its pooled map into columns [block*C, (block+1)*C) of its oh*ow rows and ZEROS into the other blocks of those
+ * rows -- no fill launch.  `out` = the level's first row in image 0 (column 0 of the matrix), out_n_stride = elements between images. */
+int arseg_adaptive_avgpool_blockrow_fwd(const float *in, int in_ld, float *out, long long out_n_stride, int N, int H, int W, int C,
+                                        int oh, int ow, int n_blocks, int block, arseg_stream_t stream);
 /* PSPModule priors (model/pspnet.py:27-30), folded: with t[n][off_s + i][c] the per-level maps AFTER the stage conv and
  * the level's slice of the bottleneck conv (both 1x1, i.e. linear and commuting with bilinear upsampling), this writes
  * out[n,y,x,c] = sum_s upsample_bilinear(align_corners=False)(t_s[n])(y,x,c); off_s = sum_{j<s} sizes[j]^2 (host array). */

@@ -228,3 +228,50 @@ def test_alter_res16_golden(dev, golden, manifest, dtype):
     assert e <= {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype] * float(np.abs(g["out"]).max())
     assert agree >= {torch.float16: 0.99, torch.bfloat16: 0.93}[dtype]
     assert int(hist.sum()) == int((label != 255).sum())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bisenet16_odd_sizes_golden(dev, golden, manifest, dtype):
+    """The odd-size path of BASELINE configs[4] (0.3x: 307x614 -> 40x78 maps; here the reference's 67x131 fixture G6-odd, whose
+    16/32-stride maps need the re-interpolation branches of bisenet.py:298) with 16-bit storage, HR branch and LR phase 1."""
+    go = golden("g6_biseodd")
+    rel = {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]
+    hr, lr = _bise16(manifest, dev, False, dtype), _bise16(manifest, dev, True, dtype)
+    with torch.no_grad():
+        oo, _, _, fo = hr(t(go["x"]).to(dev))
+        a16, _, mid = lr.forward_phase1(t(go["x"]).to(dev))
+    assert fo.dtype == dtype and mid.dtype == dtype and tuple(mid.shape) == go["mid"].shape
+    e = {"hr_out": (maxdiff(oo[..., ::2, ::2], go["hr_out_s2"]), float(np.abs(go["hr_out_s2"]).max())),
+         "hr_feat_fuse": (maxdiff(fo.float(), go["hr_feat_fuse"]), float(np.abs(go["hr_feat_fuse"]).max())),
+         "mid": (maxdiff(mid.float(), go["mid"]), float(np.abs(go["mid"]).max())),
+         "aux16": (maxdiff(a16[..., ::4, ::4], go["aux16_s4"]), float(np.abs(go["aux16_s4"]).max()))}
+    print(f"\n[{dtype}] odd sizes: " + ", ".join(f"{k} err {v[0]:.3e} (max {v[1]:.1f})" for k, v in e.items()))
+    for k, (err, mag) in e.items():
+        assert err <= rel * mag, k
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_phase2_warp16_noninteger_ratio(dev, manifest, dtype):
+    """Warp + CReFF + head on 16-bit features at a non-integer LR/HR ratio (configs[4]: a 40x78 LR map under a 128x256 keyframe
+    feature; here 10x18 under 21x37) against the oracle evaluated on the same rounded tensors: the stage itself computes in fp32,
+    so the only difference to the oracle is the kernel's arithmetic (<= 2e-4 of the magnitude)."""
+    from arseg_amd import ops
+    from oracle import cpu_ref
+
+    lr = _bise16(manifest, dev, True, dtype)
+    sd = {k: v.detach().cpu().float() for k, v in lr.state_dict().items()}
+    Hp, Wp, hp, wp, C = 21, 37, 10, 18, 256
+    g = np.random.Generator(np.random.PCG64(17))
+    mvq = torch.from_numpy((g.integers(-6, 7, (1, Hp * 8, Wp * 8, 2)) * 4).astype(np.int16))
+    ref = rnd(31, 1, C, Hp, Wp).to(dtype)
+    mid = rnd(32, 1, C, hp, wp).to(dtype)
+    with torch.no_grad():
+        lo, p_c8 = lr.phase2_warp(mid.permute(0, 2, 3, 1).contiguous().to(dev), [ref.permute(0, 2, 3, 1).contiguous().to(dev)[0]], mvq.to(dev),
+                                  upsample=False)
+        warped = cpu_ref.warp_feature(ref.float(), cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq), Hp, Wp))
+        want_p = cpu_ref.my_attention(sd, "fuse_attention.", warped, mid.float(), 7, 7)
+        want_lo = torch.nn.functional.conv2d(want_p, sd["conv_out.conv_out.weight"], sd["conv_out.conv_out.bias"])
+    from arseg_amd import _lib
+    e_p, e_l = maxdiff(ops.from_c8(p_c8, _lib.NCHW), want_p), maxdiff(lo, want_lo)
+    print(f"\n[{dtype}] phase2_warp 10x18 -> 21x37: p err {e_p:.3e} (max {float(want_p.abs().max()):.1f}), head logits err {e_l:.3e}")
+    assert e_p <= 2e-4 * float(want_p.abs().max()) and e_l <= 2e-4 * max(float(want_lo.abs().max()), 1.0)

@@ -254,6 +254,33 @@ def test_eval_alter_res_undamped_golden(dev, golden, manifest, kind):
     assert np.array_equal(pred.cpu().long().numpy()[safe], g["preds"][safe])
 
 
+def test_evaluator_range_fallback(dev, golden, manifest, monkeypatch):
+    """An evaluation pass whose activations leave the split-fp16 operand range (a frame scaled by 3e5) is repeated on the fp32 back end:
+    the mIoU equals the one computed under set_conv_math("f32") from the start, and an in-range pass is not repeated."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops
+
+    g = golden("g7_alter_psp")
+    hr = _psp(manifest, dev, False)
+    img, label = t(g["ref"]), t(g["label"])
+    calls = []
+    orig = ops.set_conv_math
+    monkeypatch.setattr(ops, "set_conv_math", lambda name: (calls.append(name), orig(name))[1])
+    with torch.no_grad():
+        ev.EvalConstRes(scale=1.0)(hr, [(img, label, None)], 12)
+        assert calls == []                                       # in range: one pass
+        m_big = ev.EvalConstRes(scale=1.0)(hr, [(img * 3e5, label, None)], 12)
+        assert calls and calls[0] == "f32"                       # the device word was set: repeated on the fp32 MFMA
+        prev = orig("f32")
+        try:
+            m_f32 = ev.EvalConstRes(scale=1.0)(hr, [(img * 3e5, label, None)], 12)
+        finally:
+            orig(prev)
+        with pytest.raises(Exception):
+            ev.EvalConstRes(scale=1.0)(hr, iter([(img * 3e5, label, None)]), 12)      # a one-shot iterator cannot be replayed
+    assert m_big == m_f32 or (m_big != m_big and m_f32 != m_f32)
+
+
 def test_modules_fail_loudly_off_gpu(manifest):
     """No CPU fallback: a forward on CPU tensors / CPU parameters raises instead of silently computing elsewhere."""
     from arseg_amd import _lib

@@ -618,9 +618,10 @@ def test_conv2d_f16x3_range_boundaries(dev):
 
 
 def test_conv2d_range_guard(dev, monkeypatch):
-    """ARSEG_CONV_RANGE_GUARD: a conv whose input leaves the split-fp16 operand range is evaluated with the fp32 MFMA back end.  Input
-    magnitudes up to 1e6 (beyond the 131008 clamp of the direct plans, far beyond the Winograd route's range): without the guard the
-    result is the conv of the clamped input, with it the result is fp32-grade."""
+    """Operand range of the split-fp16 back end.  Input magnitudes up to 1e6 (beyond the 131008 clamp of the direct plans, far beyond the
+    Winograd route's range): the f16x3 result is the conv of the clamped input -- and the kernels say so through the sticky device word
+    (default mode: no host sync per conv; one read by ops.range_tripped()), after which the fp32 back end gives the fp32-grade result.
+    In-range inputs never set the word.  The round-2 validation mode (ARSEG_CONV_RANGE_GUARD=host) still falls back per layer."""
     from arseg_amd import _lib, ops
     from arseg_amd.packing import PackedConv
 
@@ -630,17 +631,55 @@ def test_conv2d_range_guard(dev, monkeypatch):
     x = t((g.standard_normal((1, 64, 12, 20)) * np.exp(g.uniform(np.log(1e2), np.log(1e6), (1, 64, 12, 20)))).astype(np.float32))
     want = F.conv2d(x.double(), w.double(), padding=1)
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    rel = lambda y, ref: float((y.permute(0, 3, 1, 2).cpu().double() - ref).abs().max() / ref.abs().max())
     prev = ops.set_conv_math("f16x3")
     try:
-        e_off = float((ops.conv2d(xd, pc).permute(0, 3, 1, 2).cpu().double() - want).abs().max() / want.abs().max())
-        monkeypatch.setattr(ops, "_RANGE_GUARD", True)
-        e_on = float((ops.conv2d(xd, pc).permute(0, 3, 1, 2).cpu().double() - want).abs().max() / want.abs().max())
-        small = ops.conv2d(xd * 1e-4, pc)                      # inside the range: the guard leaves the f16x3 plan alone
+        assert ops._RANGE_MODE == "device"
+        ops.range_tripped()                                     # clear
+        small = ops.conv2d(xd * 1e-4, pc)                      # inside the range
+        assert not ops.range_tripped()
+        e_off = rel(ops.conv2d(xd, pc), want)
+        assert ops.range_tripped() and not ops.range_tripped()      # set by the kernels, cleared by the read
+        ops.set_conv_math("f32")
+        e_f32 = rel(ops.conv2d(xd, pc), want)
+        assert not ops.range_tripped()
+        ops.set_conv_math("f16x3")
+        for cfg in (1, 13):                                    # an implicit-GEMM plan and a patch-resident plan, explicitly
+            ops.conv2d(xd, pc, tile_cfg=cfg, split_k=1)
+            assert ops.range_tripped(), cfg
+            ops.conv2d(xd * 1e-4, pc, tile_cfg=cfg, split_k=1)
+            assert not ops.range_tripped(), cfg
+        monkeypatch.setattr(ops, "_RANGE_GUARD", True)          # the host-synchronising validation mode
+        e_host = rel(ops.conv2d(xd, pc), want)
         assert ops._math == _lib.MATH_F16X3
     finally:
         ops.set_conv_math(prev)
-    assert e_on <= 1e-5 and e_off > 1e-2, (e_on, e_off)
-    assert float((small.permute(0, 3, 1, 2).cpu().double() - want * 1e-4).abs().max() / (want.abs().max() * 1e-4)) <= 1e-5
+        ops.range_tripped()
+    assert e_f32 <= 1e-5 and e_host <= 1e-5 and e_off > 1e-2, (e_f32, e_host, e_off)
+    assert rel(small, want * 1e-4) <= 1e-5
+
+
+def test_range_guard_winograd_and_evaluator(dev):
+    """The Winograd route multiplies transformed activations (up to ~100x the input, stored scaled by 2^-4): its batched GEMM watches
+    those (the evaluator's fallback: tests/test_gpu_models.py::test_evaluator_range_fallback)."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    w = rnd(198, 64, 64, 3, 3, scale=0.05)
+    pc = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_NONE, 0.0, dev)
+    if getattr(pc, "wino_u", None) is None:
+        pytest.skip("no Winograd weights for this layer")
+    x = rnd(199, 1, 24, 32, 64).to(dev)
+    out = torch.empty((1, 24, 32, 64), dtype=torch.float32, device=dev)
+    prev = ops.set_conv_math("f16x3")
+    try:
+        ops.range_tripped()
+        ops._conv_wino(x, pc, None, out, 1, 24, 32)
+        assert not ops.range_tripped()
+        ops._conv_wino(x * 3e5, pc, None, out, 1, 24, 32)       # |V| * 2^-4 beyond 65504 for some tiles
+        assert ops.range_tripped()
+    finally:
+        ops.set_conv_math(prev)
 
 
 @pytest.mark.parametrize("H,W,h,w", [(36, 48, 18, 24), (35, 47, 17, 23), (20, 30, 20, 30)])

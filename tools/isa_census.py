@@ -6,9 +6,10 @@
 
 A segment is the code between two s_barrier instructions of the kernel's outermost loop (the tile loop).  Counts are
 static: every instruction of the segment once, inner loops once (their trip counts are listed by the caller), rarely
-taken blocks included.  `issue_cycles` prices a wave-instruction by the MI355X guide's per-SIMD issue costs (plain VALU 2,
-packed fp32 / fp64 / transcendental 4, DS by the LDS table, MFMA 16x16x32 f16 16, VMEM 4) -- a floor for one wave's
-issue time, not a simulation.
+taken blocks included.  `issue_cycles` prices a wave-instruction by issue costs MEASURED on MI355X with four waves per SIMD
+(scratch micro-benchmark, round 3: v_and / v_mov 2.4 cycles, v_fma_f32 3.0, v_pk_fma_f32 / v_mov_dpp / v_cvt_pkrtz 4.24,
+v_exp_f32 8.2; fp64 taken as 8), DS by the guide's LDS table, MFMA 16x16x32 f16 16, VMEM 4 -- a floor for one wave's issue
+time, not a simulation.
 """
 import argparse
 import collections
@@ -28,24 +29,24 @@ def classify(op, text):
     if op.startswith("v_"):
         dpp = "row_sh" in text or "quad_perm" in text or "row_bcast" in text or "dpp" in op
         if op.startswith("v_pk_"):
-            return "valu_pk", 4
+            return "valu_pk", 4.24
         if op.endswith("_f64") or "_f64_" in op:
-            return "valu_f64", 4
+            return "valu_f64", 8
         if op.startswith(TRANS):
-            return "valu_trans", 4
+            return "valu_trans", 8.2
         if op.startswith("v_cvt") or op.startswith("v_fma_mix"):
-            return "valu_cvt", 2
+            return "valu_cvt", 4.24
         if op.startswith("v_permlane") or op.startswith("v_readfirstlane") or op.startswith("v_readlane") or op.startswith("v_writelane"):
-            return "valu_lane", 2
+            return "valu_lane", 4.24
         if dpp:
-            return "valu_dpp", 2
+            return "valu_dpp", 4.24
         if op.startswith(("v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_mac_f32", "v_max_f32", "v_min_f32")):
-            return "valu_f32", 2
+            return "valu_f32", 3.0
         if op.startswith(("v_mov", "v_accvgpr")):
-            return "valu_mov", 2
+            return "valu_mov", 2.4
         if op.startswith("v_cmp") or op.startswith("v_cndmask"):
-            return "valu_cmpsel", 2
-        return "valu_int", 2
+            return "valu_cmpsel", 2.4
+        return "valu_int", 2.4
     if op.startswith("ds_"):
         return ("ds_read" if "read" in op or "bpermute" in op else "ds_write"), DS_COST.get(op, 4)
     if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
@@ -118,17 +119,17 @@ def main():
     for k, s in enumerate(segs):
         nm = names[k] if k < len(names) else "seg%d" % k
         s["name"] = nm
-        rows.append([nm] + [str(s["counts"].get(x, 0)) for x in keys])
+        rows.append([nm] + [str(round(s["counts"].get(x, 0))) for x in keys])
     tot = collections.Counter()
-    for s in segs[:-1]:
+    for s in segs:          # (the last segment runs to s_endpgm: the tile loop's final phase plus the few instructions after the loop)
         tot.update(s["counts"])
-    rows.append(["TOTAL(loop)"] + [str(tot.get(x, 0)) for x in keys])
+    rows.append(["TOTAL"] + [str(round(tot.get(x, 0))) for x in keys])
     w = [max(len(r[c]) for r in [hdr] + rows) for c in range(len(hdr))]
     for r in [hdr] + rows:
         print("  ".join(x.rjust(w[c]) for c, x in enumerate(r)))
     if args.json:
         json.dump({"kernel": args.kernel, "asm_first_line": meta["first_line"], "segments": segs, "total_loop": dict(tot),
-                   "pricing": "per wave-instruction issue cycles on one SIMD: VALU 2, packed/f64/transcendental 4, MFMA 16x16x32 16, DS by the LDS table, VMEM 4"},
+                   "pricing": "per wave-instruction issue cycles on one SIMD, measured with 4 waves/SIMD: int/mov/cmp 2.4, fma_f32 3.0, pk_f32/dpp/cvt 4.24, transcendental 8.2, f64 8 (assumed); MFMA 16x16x32 16, DS by the LDS table, VMEM 4"},
                   open(args.json, "w"), indent=1)
 
 
