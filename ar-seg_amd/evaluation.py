@@ -169,7 +169,7 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
     """
     lr_net = _unwrap(lr_net)
     B, _, H, W = imgs.shape
-    sub = int(os.environ.get("ARSEG_LR_SUBBATCH", "0"))
+    sub = ops.config.lr_subbatch
     if 0 < sub < B:                       # optional: bound the working set (Winograd V / M tensors) per pass
         outs = [alter_res_batch_fast(lr_net, ref_ps[i:i + sub], imgs[i:i + sub], mv_qs[i:i + sub], scale) for i in range(0, B, sub)]
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])

@@ -10,6 +10,7 @@ Internal activation layout is NHWC: tensors of shape ``[N, H, W, C]`` (C contigu
 from __future__ import annotations
 
 import ctypes
+import dataclasses
 import os
 from typing import Optional, Tuple
 
@@ -21,6 +22,63 @@ from ._lib import ConvDesc, check
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------
+# configuration: every knob of the Python host layer in one object (the library reads no environment variables)
+# ----------------------------------------------------------------------------------------------
+@dataclasses.dataclass
+class Config:
+    """``ops.config`` -- initialised once from the environment (variable in brackets), changed at run time with ``ops.configure(...)``.
+
+    conv_math        [ARSEG_CONV_MATH = f16x3 | f32 | f16]     MFMA back end of the fp32 conv GEMMs (f16x3: hi/lo split, 3 fp16 MFMAs per
+                     product; f32: v_mfma_f32_32x32x2_f32; f16: reduced-precision comparison point)
+    conv_autotune    [ARSEG_CONV_AUTOTUNE = 1 | 0]              per-shape plans timed on first use (0: the library's tile heuristic)
+    conv_find        [ARSEG_CONV_FIND = native | python]        who times the candidate plans: arseg_conv2d_find or the host loop
+    conv_winograd    [ARSEG_CONV_WINOGRAD = 1 | 0]              let the tuner consider Winograd F(4x4,3x3)
+    conv_up2_taps    [ARSEG_CONV_UP2_TAPS = 1 | 0]              let the tuner consider the tap decomposition for convs after a x2 upsample
+    conv_range_guard [ARSEG_CONV_RANGE_GUARD = device | host | 0]   operand range of the f16x3 back end: sticky device word read by
+                     ops.range_tripped() (default) / amax + host sync per conv with an immediate fp32 fallback / off
+    conv_plan_file   [ARSEG_CONV_PLAN_FILE = <json>]            persist the tuned plans
+    creff_impl       [ARSEG_CREFF_IMPL = mfma | valu]           pin one of the two CReFF kernels for C >= 128 (A/B measurements, tests)
+    creff_tile_rows  [ARSEG_CREFF_TY = 8 | 16]                  pin the tile height of the matrix-core CReFF kernel
+    lr_subbatch      [ARSEG_LR_SUBBATCH = n]                    evaluate the LR batch of a GOP in slices of n frames (bounds the working set)
+    (ARSEG_HIP_LIB = <path> selects an alternative library build; it is read by _lib before anything is loaded.)"""
+    conv_math: str = "f16x3"
+    conv_autotune: bool = True
+    conv_find: str = "native"
+    conv_winograd: bool = True
+    conv_up2_taps: bool = True
+    conv_range_guard: str = "device"
+    conv_plan_file: Optional[str] = None
+    creff_impl: str = ""
+    creff_tile_rows: int = 0
+    lr_subbatch: int = 0
+
+    @classmethod
+    def from_env(cls):
+        e = os.environ.get
+        return cls(conv_math=e("ARSEG_CONV_MATH", "f16x3"), conv_autotune=e("ARSEG_CONV_AUTOTUNE", "1") != "0",
+                   conv_find=e("ARSEG_CONV_FIND", "native"), conv_winograd=e("ARSEG_CONV_WINOGRAD", "1") != "0",
+                   conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0",
+                   conv_range_guard={"1": "host", "host": "host", "0": "off", "off": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), "device"),
+                   conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=int(e("ARSEG_CREFF_TY", "0") or 0),
+                   lr_subbatch=int(e("ARSEG_LR_SUBBATCH", "0") or 0))
+
+
+config = Config.from_env()
+
+
+def configure(**kw):
+    """Change knobs of ``ops.config`` at run time (names as in Config); returns the previous values of the ones changed."""
+    prev = {}
+    for k, v in kw.items():
+        if not hasattr(config, k):
+            raise _lib.ArsegError(f"unknown configuration key {k!r}")
+        prev[k] = getattr(config, k)
+        setattr(config, k, v)
+    _apply_config()
+    return prev
 
 
 # ----------------------------------------------------------------------------------------------
@@ -361,9 +419,9 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
         wf, bf = head
         n_cls = wf.shape[0]
         logits = torch.empty((N, n_cls, Hp, Wp), dtype=torch.float32, device=hr_c8.device)
-    # kernel choice: explicit arguments of the ABI; the environment knobs (A/B measurements, tests) are read here, not in the library
-    impl = {"mfma": 1, "valu": 2}.get(os.environ.get("ARSEG_CREFF_IMPL", ""), 0)
-    tile_rows = int(os.environ.get("ARSEG_CREFF_TY", "0") or 0)
+    # kernel choice: explicit arguments of the ABI; the knobs (A/B measurements, tests) live in ops.config, not in the library
+    impl = {"mfma": 1, "valu": 2}.get(config.creff_impl, 0)
+    tile_rows = config.creff_tile_rows
     _launch("creff", _lib.load().arseg_creff_fwd_ex, _ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
                                       _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
                                       1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, impl, tile_rows if tile_rows in (8, 16) else 0, _stream(),
@@ -456,11 +514,11 @@ def _nhwc_ld(t: torch.Tensor) -> int:
 # Per-shape launch plans (tile shape, LDS buffering, split-K).  The library's built-in heuristic is good to ~10 %; the
 # first time a conv shape is seen on a device the candidates are timed with HIP events and the fastest is cached
 # (what MIOpen calls "find").  ARSEG_CONV_AUTOTUNE=0 keeps the heuristic.
-_AUTOTUNE = os.environ.get("ARSEG_CONV_AUTOTUNE", "1") != "0"
+_AUTOTUNE = config.conv_autotune
 # Which MFMA back end evaluates the fp32 GEMMs (include/arseg_hip.h: enum arseg_math): "f16x3" = fp32 emulated with three
 # fp16 MFMAs on hi/lo-split operands (22-bit significands, fp32 accumulate), "f32" = the fp32 MFMA.
 _MATH_NAMES = {"f32": _lib.MATH_F32, "f16x3": _lib.MATH_F16X3, "f16": _lib.MATH_F16}      # "f16": reduced precision (plain fp16 operands)
-_math = _MATH_NAMES[os.environ.get("ARSEG_CONV_MATH", "f16x3")]
+_math = _MATH_NAMES[config.conv_math]
 
 
 def set_conv_math(name: str) -> str:
@@ -468,6 +526,7 @@ def set_conv_math(name: str) -> str:
     global _math
     prev = [k for k, v in _MATH_NAMES.items() if v == _math][0]
     _math = _MATH_NAMES[name]
+    config.conv_math = name
     return prev
 # Operand-range safety of the split-fp16 back end (include/arseg_hip.h, ARSEG_MATH_F16X3: the hi/lo pair carries 22 bits up to |x| = 65504
 # and clamps beyond 131008; the Winograd route multiplies TRANSFORMED activations, ~10x the input).
@@ -476,7 +535,7 @@ def set_conv_math(name: str) -> str:
 #     ops.range_tripped() (one sync) and repeats the batch under ops.set_conv_math("f32") -- evaluation.Eval*Res do, bench.py reports it.
 #   * ARSEG_CONV_RANGE_GUARD=host: the round-2 validation mode -- amax of every conv input with one host sync per conv, the layer is
 #     evaluated with the fp32 MFMA back end at once (not capturable).   * ARSEG_CONV_RANGE_GUARD=0: off.
-_RANGE_MODE = {"1": "host", "host": "host", "0": "off", "off": "off"}.get(os.environ.get("ARSEG_CONV_RANGE_GUARD", "device"), "device")
+_RANGE_MODE = config.conv_range_guard
 _RANGE_GUARD = _RANGE_MODE == "host"
 _RANGE_LIMIT = 2.0e4
 _range_words = {}
@@ -513,7 +572,7 @@ def range_tripped(device=None, reset: bool = True) -> bool:
     return hit
 
 
-_PLAN_FILE = os.environ.get("ARSEG_CONV_PLAN_FILE")       # optional: persist tuned plans (skips the trial launches next time)
+_PLAN_FILE = config.conv_plan_file       # optional: persist tuned plans (skips the trial launches next time)
 
 
 class _PlanCache(dict):
@@ -538,7 +597,7 @@ class _PlanCache(dict):
 
 
 _conv_plans = _PlanCache()
-_NATIVE_FIND = os.environ.get("ARSEG_CONV_FIND", "native") != "python"      # "python": time the candidates from the host loop below instead
+_NATIVE_FIND = config.conv_find != "python"      # "python": time the candidates from the host loop below instead
 _PATCH_CFGS = (13, 14, 15, 16)      # arseg_conv_desc.tile_cfg of the patch-resident 3x3 kernel (the only direct plans with a fused x2 upsample)
 
 
@@ -668,7 +727,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         taps_ok = (x_low is not None and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
                    and pc.dil == 1 and pc.cout % 4 == 0)
         plan = _conv_plans.get(key)
-        if (plan == "wino" and not wino_ok) or (plan in ("taps", "tapsf") and not taps_ok) or (plan == "tapsf" and not _UP2_FUSED):      # a persisted plan whose route is switched off: re-tune
+        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or plan == "tapsf":      # a persisted plan whose route is switched off / gone: re-tune
             plan = None
         if plan is None:
             plan = find_native() if _NATIVE_FIND else None
@@ -705,14 +764,6 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "taps"
                 except _lib.ArsegError:
                     pass
-            if taps_ok and _UP2_FUSED and Cin == 64 and pc.cout % 16 == 0 and math == _lib.MATH_F16X3:
-                try:
-                    t_best = _time({"wino": lambda: launch_wino(record=False), "taps": lambda: launch_taps(record=False)}.get(
-                        plan, lambda: launch(*plan, record=False)))
-                    if _time(lambda: _conv_up2_fused(x_low, pc, out, record=False)) < t_best:
-                        plan = "tapsf"
-                except _lib.ArsegError:
-                    pass
             _conv_plans[key] = plan
         global _layer_tag
         outer_tag = _layer_tag          # the tap-decomposed route calls conv2d for its low-resolution GEMM: the outermost layer keeps the tag
@@ -721,8 +772,6 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         try:
             if plan == "wino":
                 launch_wino()
-            elif plan == "tapsf":
-                _conv_up2_fused(x_low, pc, out)
             elif plan == "taps":
                 launch_taps()
             else:
@@ -797,7 +846,7 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
     return out
 
 
-_WINOGRAD = os.environ.get("ARSEG_CONV_WINOGRAD", "1") != "0"
+_WINOGRAD = config.conv_winograd
 
 
 def _time(fn, reps=6):
@@ -860,8 +909,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
        _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, 1.0 / vs, _stream())
 
 
-_UP2_TAPS = os.environ.get("ARSEG_CONV_UP2_TAPS", "1") != "0"
-_UP2_FUSED = os.environ.get("ARSEG_CONV_UP2_FUSED", "0") == "1"      # LDS-resident tap planes for 64 input channels: on par with the direct plan, opt-in
+_UP2_TAPS = config.conv_up2_taps
 
 
 def _conv_up2_taps(x_low, pc, out, record=True):
@@ -876,21 +924,6 @@ def _conv_up2_taps(x_low, pc, out, record=True):
         _launch("up2_tap_gather", lib.arseg_upconv3x3_tap_gather_fwd, *args)
     else:
         check(lib.arseg_upconv3x3_tap_gather_fwd(*args), "up2_tap_gather")
-
-
-def _conv_up2_fused(x_low, pc, out, record=True):
-    """The tap decomposition with the tap planes kept in LDS (arseg_upconv3x3_fused_fwd): 64 input channels, f16x3 arithmetic."""
-    if _math != _lib.MATH_F16X3:
-        raise _lib.ArsegError("fused tap route: f16x3 arithmetic only")
-    lib = _lib.load()
-    n, h, w, cin = x_low.shape
-    pt = pc.taps()
-    args = (_ptr(x_low), _nhwc_ld(x_low), _ptr(pt.w_h3), _ptr(pt.scale_h3), _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, cin,
-            pc.cout, pc.act, pc.slope, _stream())
-    if record:
-        _launch("conv2d", lib.arseg_upconv3x3_fused_fwd, *args, flops=2 * n * h * w * cin * 9 * pc.cout)
-    else:
-        check(lib.arseg_upconv3x3_fused_fwd(*args), "upconv3x3_fused")
 
 
 def _tune_conv(launch, pc, m, allow_patch=True):
@@ -1120,3 +1153,12 @@ def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int
     _launch("argmax_confusion", _lib.load().arseg_argmax_confusion_fwd, _ptr(logits), _ptr(label), _ptr(pred), _ptr(hist if label is not None else None), N,
                                                  n_cls, h, w, H, W, ignore_label, 1 if align_corners else 0, _stream())
     return pred, hist
+
+
+def _apply_config():
+    """Push ``ops.config`` into the module-level switches the hot paths read."""
+    global _AUTOTUNE, _math, _RANGE_MODE, _RANGE_GUARD, _NATIVE_FIND, _WINOGRAD, _UP2_TAPS
+    _AUTOTUNE, _math = config.conv_autotune, _MATH_NAMES[config.conv_math]
+    _RANGE_MODE = config.conv_range_guard if config.conv_range_guard in ("device", "host", "off") else "device"
+    _RANGE_GUARD = _RANGE_MODE == "host"
+    _NATIVE_FIND, _WINOGRAD, _UP2_TAPS = config.conv_find != "python", config.conv_winograd, config.conv_up2_taps

@@ -245,13 +245,6 @@ int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bia
  * its transformed operand (9x the low-resolution input) and without its rounding amplification.  Cout % 4 == 0, 16-byte aligned. */
 int arseg_upconv3x3_tap_gather_fwd(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N, int h,
                                    int w, int Cout, int act, float prelu_slope, arseg_stream_t stream);
-/* The same conv with the tap planes kept in LDS (no z in HBM), for Cin == 64 (PSPUpsample up_3: at K = 64 the low-resolution GEMM is
- * memory-bound when z round-trips): in = [N,h,w,64] fp32 (row stride in_ld), w9_h3 / s9 = the stacked tap weights [9*Cout][64] in the
- * split-fp16 operand format of ARSEG_MATH_F16X3 and their per-row factors (arseg_pack_conv_weight_host on the [9*Cout,64,1,1] tap matrix,
- * then arseg_split_weight_f16x3_host), out = act(scale * conv + bias) as [N,2h,2w,Cout].  Cout % 16 == 0.  f16x3 arithmetic only;
- * ARSEG_EUNSUPPORTED for other channel counts (use the two-step route above). */
-int arseg_upconv3x3_fused_fwd(const float *in, int in_ld, const void *w9_h3, const float *s9, const float *scale, const float *bias, float *out,
-                              int out_ld, int N, int h, int w, int Cin, int Cout, int act, float prelu_slope, arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
 
 /* Host-side weight preparation (the "weight packer"; CPU pointers).

@@ -111,7 +111,7 @@ def test_weight_packer_host_functions():
 
 def test_packed_conv_taps_layout_and_oracle():
     """PackedConv.taps(): row t*Cout + co of the stacked 1x1 weights = W[co, :, t//3, t%3] (the layout include/arseg_hip.h documents for
-    arseg_upconv3x3_tap_gather_fwd / arseg_upconv3x3_fused_fwd), and the identity the route rests on, checked on the CPU with torch ops:
+    arseg_upconv3x3_tap_gather_fwd), and the identity the route rests on, checked on the CPU with torch ops:
     conv3x3(Up(x)) == sum_t shift_t(Up(W_t x)) with zero padding of the UPSAMPLED image."""
     from arseg_amd import _lib
     from arseg_amd.packing import PackedConv
