@@ -335,10 +335,11 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     _log("timed region")
     steps_requested = steps
     elapsed, outs = timed_region(steps)
-    if full and elapsed < MIN_TIMED_S:
+    min_s = MIN_TIMED_S if full else 0.3 * MIN_TIMED_S          # variant lines: a shorter window, still far above launch jitter
+    if elapsed < min_s:
         # the requested K steps are too short a window to trust (0.12 s at --steps 20): time a whole multiple of K that lasts
         # >= 1 s instead; the multiple follows from the max-over-ranks time, so every rank runs the same number of steps
-        steps = steps_requested * int(math.ceil(1.05 * MIN_TIMED_S / max(elapsed, 1e-6)))
+        steps = steps_requested * int(math.ceil(1.05 * min_s / max(elapsed, 1e-6)))
         elapsed, outs = timed_region(steps)
 
     # N = 1 replays a captured HIP graph, N > 1 enqueues eagerly around the RCCL exchange: the eager rate of the same step at N = 1 is
@@ -575,7 +576,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         result["parity"] = {"max_abs_err_logprobs": float((got - o_out).abs().max()),
                             "max_abs_err_keyframe_feature": float((ref_gpu - ref_cpu).abs().max()),
                             "argmax_agreement": float((got.argmax(1) == o_out.argmax(1)).float().mean()),
-                            "tolerance": 1e-3}
+                            "tolerance": 1e-3 if storage == "f32" else None}
+        if storage != "f32":
+            result["parity"]["note"] = "16-bit storage is reduced precision by construction: the error against the fp32 oracle is stated, not bounded by 1e-3"
         if fused_tail:
             result["parity"]["fused_tail_label_agreement"] = float((pred0 == o_out.argmax(1)).float().mean())
     return result
