@@ -58,15 +58,6 @@ constexpr float LOG2E = 1.44269504088896340736f;
 #ifndef RR_GB
 #define RR_GB 5       // gather units per later batch
 #endif
-#ifndef RR_PV2
-#define RR_PV2 0      // 1: P.V block-major with four accumulators (see phase 7; measured 1.5 % slower); 0: chunk-major
-#endif
-#ifndef RR_BORDER
-#define RR_BORDER 1
-#endif
-#ifndef RR_DEPHASE
-#define RR_DEPHASE 0
-#endif
 
 struct RRParams {
     const float *ref[MAXN];       // un-warped keyframe feature of each frame, NHWC [Hp][Wp][64]
@@ -211,14 +202,6 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             dma4_glb(p.mv + ((size_t)n_ * p.H * p.W + (size_t)gy * p.W + gx) * 2, lds_addr(TapO) + (unsigned)__builtin_amdgcn_readfirstlane(tq >> 6) * 256u);
     };
     if (t_lo + slot < t_hi) mv_fetch(t_lo + slot);
-#if RR_DEPHASE > 0
-    // Every workgroup walks tiles of equal cost, so all 256 CUs sit in the same phase at the same time: the gather phases of the whole
-    // chip hit the L2s together (and leave them idle together).  Half of each XCD's workgroups start RR_DEPHASE x 8k cycles late.
-    if (slot & 1) {
-#pragma unroll 1
-        for (int i = 0; i < RR_DEPHASE; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   for (int tile = t_lo + slot; tile < t_hi; tile += nslot) {
     // Everything derived from the thread id is recomputed per phase from an opaque copy: left alone, LLVM hoists the per-lane
@@ -512,8 +495,8 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
 
     // ------------------------------------------------------------------ phases 4 / 6: key (value) records of the whole region
     // Interior tiles (every record of the 22 x 22 region inside the image: all but the frame's border tiles) need no padding mask -- a
-    // compare, a scalar and and four selects per row.  With RR_BORDER the row loop stores unmasked records and border tiles (a tile-uniform
-    // branch) zero their out-of-image records afterwards.
+    // compare, a scalar and and four selects per row: the row loop stores unmasked records and border tiles (a tile-uniform branch) zero
+    // their out-of-image records afterwards.
     const bool rec_interior = ty0 >= 3 && tx0 >= 3 && ty0 + TY + 3 <= Hp && tx0 + TX + 3 <= Wp;
     auto conv_records = [&](const float *wt, const float *bs, int kpl) {
         RR_TID(t);
@@ -551,17 +534,10 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             acc = fma4(w[6], l2, acc); acc = fma4(w[7], h[j + 2], acc); acc = fma4(w[8], r2, acc);
             u32x2 hi, lo;
             split4(acc, hi, lo);
-#if RR_BORDER
             if (wr_ok) dst[j * R3W] = u32x4{hi.x, hi.y, lo.x, lo.y};
-#else
-            // the unfold's zero padding, as a mask on the packed record (a select on acc makes hipcc branch around the FMAs)
-            const unsigned in = (col_in && (unsigned)(gy + j) < (unsigned)Hp) ? 0xFFFFFFFFu : 0u;
-            if (wr_ok) dst[j * R3W] = u32x4{hi.x & in, hi.y & in, lo.x & in, lo.y & in};
-#endif
             l0 = l1; r0 = r1; l1 = l2; r1 = r2;
             __builtin_amdgcn_sched_barrier(0);      // row by row: hoisting the neighbour moves of all 13 rows would spill the columns
         }
-#if RR_BORDER
         if (!rec_interior) {                        // the unfold's zero padding: records outside the image are zero
             unsigned zz = 0u;
             asm volatile("" : "+v"(zz));            // (defined here: hipcc otherwise keeps a zero vector in four registers across the whole tile loop)
@@ -569,7 +545,6 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             for (int j = 0; j < 11; ++j)
                 if (wr_ok && !(col_in && (unsigned)(gy + j) < (unsigned)Hp)) dst[j * R3W] = u32x4{zz, zz, zz, zz};
         }
-#endif
     };
     if (RR_ON(4)) conv_records(p.wk, p.bk, KPLK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the next tile's motion vectors have landed long ago
@@ -705,52 +680,11 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                     }
                 }
             };
-#if RR_PV2
-            // Block-major: the swapped weight operand (p_lo | p_hi) of a block is formed once (4 v_mov) and used by all four channel chunks --
-            // chunk-major order swapped the VALUE operand instead, 4 v_mov between every pair of dependent MFMAs (112 per tile).  Four
-            // independent accumulators, eight transpose reads in flight per block.  The residual taps of two chunks are requested ahead of
-            // the MFMAs, the others while the first epilogues run.
-            f32x4 tp[2][4];
-#pragma unroll
-            for (int c = 0; c < 2; ++c) { tp[c][0] = lr_tap(o00, c); tp[c][1] = lr_tap(o01, c); tp[c][2] = lr_tap(o10, c); tp[c][3] = lr_tap(o11, c); }
-            f32x4 acc[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const unsigned char *va0 = reinterpret_cast<const unsigned char *>(BIGu + (q & 3) * KPLV);
-#pragma unroll
-            for (int b = 0; b < 7; ++b) {
-                const h16x8 pb = __builtin_bit_cast(h16x8, P[b]), pbs = __builtin_bit_cast(h16x8, u32x4{P[b].z, P[b].w, P[b].x, P[b].y});
-                const unsigned vo = vrec(b);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned char *va = va0 + c * (4 * KPLV * 16);
-                    const h16x8 a = RR_ON(12) ? pack8(lds_tr16(va + vo), lds_tr16(va + vo + 8)) : pack8(u32x2{vo, vo}, u32x2{vo, (unsigned)c});
-                    if (RR_ON(10)) {
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pb, acc[c], 0, 0, 0);
-                        acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, pbs, acc[c], 0, 0, 0);
-                    } else {
-                        acc[c] += __builtin_bit_cast(f32x4, a) + __builtin_bit_cast(f32x4, pb);
-                    }
-                }
-            }
-            RR_STAMP(14);
+            // the four residual taps of a chunk are requested at the top of the chunk and blended BEHIND its 14 MFMAs (requested one chunk
+            // ahead and blended at the top, chunk 0 waited for its taps with nothing to cover the L2 round trip)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                if (c == 2) RR_STAMP(0);
-                const f32x4 *t4 = tp[c & 1];
-                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * t4[0] + lx * t4[1]) + ly * ((1.f - lx) * t4[2] + lx * t4[3]);
-                if (c < 2) { tp[c][0] = lr_tap(o00, c + 2); tp[c][1] = lr_tap(o01, c + 2); tp[c][2] = lr_tap(o10, c + 2); tp[c][3] = lr_tap(o11, c + 2); }
-                epilogue(c, lrc + acc[c] * inv);
-            }
-#else
-            // the four taps of a chunk are requested one chunk ahead: their latency hides behind the 14 MFMAs of the current one
-            f32x4 a00 = lr_tap(o00, 0), a01 = lr_tap(o01, 0), a10 = lr_tap(o10, 0), a11 = lr_tap(o11, 0);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
-                if (c < 3) {
-                    a00 = lr_tap(o00, c + 1); a01 = lr_tap(o01, c + 1); a10 = lr_tap(o10, c + 1); a11 = lr_tap(o11, c + 1);
-                }
+                const f32x4 a00 = lr_tap(o00, c), a01 = lr_tap(o01, c), a10 = lr_tap(o10, c), a11 = lr_tap(o11, c);
                 const unsigned char *va = reinterpret_cast<const unsigned char *>(BIGu + (4 * c + (q & 3)) * KPLV);
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -760,9 +694,9 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
                 }
+                const f32x4 lrc = (1.f - ly) * ((1.f - lx) * a00 + lx * a01) + ly * ((1.f - lx) * a10 + lx * a11);
                 epilogue(c, lrc + acc * inv);
             }
-#endif
         }
 
         // logits: lg[nb][i] = class 16nb + 4g + i of query q
