@@ -120,6 +120,11 @@ def load() -> ctypes.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ArsegError(f"{LIB_PATH} is missing: build it with `make -C ar-seg_amd/csrc` "
                          f"(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no fallback path.")
+    # PyTorch first: it ships its own libamdhip64.so.7 (+ HSA runtime), and the first copy of that SONAME a process loads is the one every
+    # later library binds to.  Loading this library before torch pulls in /opt/rocm's runtime instead; torch then runs on a runtime stack
+    # it was not built with and every launch fails with hipErrorNoDevice (seen with build() and smoke() in one process).
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the ABI and this binding drifted apart

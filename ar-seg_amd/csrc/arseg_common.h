@@ -12,7 +12,13 @@ static inline int arseg_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? ARSEG_OK : (int)e;
 }
-static inline hipStream_t arseg_stream(arseg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+// Every entry point converts its stream handle right before it launches: that is also where a stale error of the calling thread is dropped
+// (hipGetLastError is per thread and sticky: an unrelated earlier HIP call of the host program -- e.g. a device probe that returned
+// hipErrorNoDevice before the runtime was initialised -- would otherwise be reported as this launch's status).
+static inline hipStream_t arseg_stream(arseg_stream_t s) {
+    (void)hipGetLastError();
+    return reinterpret_cast<hipStream_t>(s);
+}
 static inline int arseg_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE function attribute: remember, per device, the largest request that has
