@@ -357,6 +357,71 @@ def test_full_size_end_to_end_headline(dev):
     assert maxdiff(out, out2) <= 2e-4 and maxdiff(p_c8, p2) <= 2e-4
 
 
+def test_full_size_camvid_ar_step(dev):
+    """The reference's own dataset size: CamVid 720x960, AR-Seg 0.5x (evaluation.py --mode 1 1 1 on camvid-psp18): keyframe HR forward,
+    one non-keyframe through downscale (360x480) -> LR backbone -> MV warp + CReFF + head, HIP against the CPU oracle, 1e-3 abs, and the
+    labels exactly wherever the oracle's top-2 margin exceeds twice the measured logit error.  The 720x960 map is 45 x 60 tiles of the fused
+    kernel; the LR map 360x480 gives odd 45x60 stride-8 maps in the backbone."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+    from oracle import cpu_ref
+
+    H, W = 720, 960
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 4)
+    synth.load_synth_weights(lr, 5)
+    sd_hr = synth.resolve_aliases({k: v.clone() for k, v in hr.state_dict().items()})
+    sd_lr = synth.resolve_aliases({k: v.clone() for k, v in lr.state_dict().items()})
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    clip = synth.make_clip(7, H, W, gop=12, mean=synth.CAMVID_MEAN, std=synth.CAMVID_STD)
+    key, img, mvq = (torch.from_numpy(clip[k][i:i + 1]) for k, i in (("frames", 0), ("frames", 11), ("mv", 11)))      # the farthest frame of the GOP
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        o_out, o_p, _, o_ref = cpu_ref.alter_res_step("psp", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), 0.5)
+        ref_p = hr(key.to(dev))[-1]
+        out, p_c8 = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), 0.5)
+    e_out = maxdiff(out, o_out)
+    assert maxdiff(ref_p, o_ref) <= 1e-3 and e_out <= 1e-3 and maxdiff(ops.from_c8(p_c8, _lib.NCHW), o_p) <= 1e-3
+    top2 = o_out.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * e_out + 1e-7
+    assert torch.equal(out.argmax(1).cpu()[safe], o_out.argmax(1)[safe])
+    assert int((~safe).sum()) <= 2e-3 * safe.numel()
+
+
+def test_full_size_bisenet_step(dev):
+    """BASELINE configs[2] shapes in fp32: BiSeNet-18 keyframe HR forward at 1024x2048, one non-keyframe through downscale (512x1024) ->
+    LR backbone -> MV resize + warp + CReFF (C = 256 at 128x256) + head + x8 upsample, HIP against the CPU oracle, 1e-3 abs; and the fused
+    evaluator tail (argmax without the full-resolution logits) exactly on the pixels whose margin exceeds twice the logit error."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse
+    from oracle import cpu_ref
+
+    H, W = 1024, 2048
+    hr, lr = BiSeNetV1(n_classes=19, backend="resnet18"), BiSeNetV1WithFuse(n_classes=19, backend="resnet18")
+    synth.load_synth_weights(hr, 6)
+    synth.load_synth_weights(lr, 7)
+    sd_hr = synth.resolve_aliases({k: v.clone() for k, v in hr.state_dict().items()})
+    sd_lr = synth.resolve_aliases({k: v.clone() for k, v in lr.state_dict().items()})
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    clip = synth.make_clip(3, H, W, gop=4, mean=synth.CITY_BISE_MEAN, std=synth.CITY_BISE_STD)
+    key, img, mvq = (torch.from_numpy(clip[k][i:i + 1]) for k, i in (("frames", 0), ("frames", 3), ("mv", 3)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        o_out, o_p, _, o_ref = cpu_ref.alter_res_step("bise", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), 0.5)
+        ref_p = hr(key.to(dev))[-1]
+        out, p_c8 = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), 0.5)
+        pred, _ = ev.alter_res_batch_pred(lr, [ops.to_nhwc(ref_p)[0]], img.to(dev), mvq.to(dev), 0.5)
+    e_out = maxdiff(out, o_out)
+    assert maxdiff(ref_p, o_ref) <= 1e-3 and e_out <= 1e-3 and maxdiff(ops.from_c8(p_c8, _lib.NCHW), o_p) <= 1e-3
+    top2 = o_out.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * e_out + 1e-6
+    assert torch.equal(pred.cpu().long()[safe], o_out.argmax(1)[safe])
+    assert int((~safe).sum()) <= 2e-3 * safe.numel()
+
+
 def test_full_size_hr_720x960(dev):
     """BASELINE configs[0] shape: PSPNet-18 HR branch on one 720x960 (CamVid) frame, HIP against the CPU oracle, 1e-3 abs."""
     from arseg_amd import synth
