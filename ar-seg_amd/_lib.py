@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARSEG_HIP_LIB", os.path.join(_HERE, "lib", "libarseg_hip.so"))   # env override: kernel experiments
 
-ABI_VERSION = 2          # ARSEG_ABI_VERSION of include/arseg_hip.h
+ABI_VERSION = 3          # ARSEG_ABI_VERSION of include/arseg_hip.h
 ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 NCHW, NHWC, C8 = 0, 1, 2

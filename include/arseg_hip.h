@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ARSEG_ABI_VERSION 2
+#define ARSEG_ABI_VERSION 3
 
 enum arseg_status {
     ARSEG_OK = 0,
