@@ -767,6 +767,53 @@ def test_upsample2x_fast_path(dev, N, H, W, C):
     assert float(big[..., :4].min()) == 3.0 and float(big[..., 4 + C:].max()) == 3.0
 
 
+# ---------------------------------------------------------------------------------------------- ops.creff_warp at C = 128 .. 512, fp32 / 16-bit inputs
+@pytest.mark.parametrize("C,Hp,Wp,hp,wp,H,W,n_cls,logsm,layout,dtype", [
+    (128, 33, 47, 17, 24, 33, 47, 19, False, "c8", torch.float32),          # two quarters, identity MV resize, odd sizes
+    (256, 24, 40, 12, 20, 192, 320, 19, False, "c8", torch.float32),        # BiSeNet: four quarters, MVs at 8x the feature resolution
+    (256, 21, 37, 10, 18, 168, 296, 19, False, "nhwc", torch.bfloat16),     # 16-bit inputs, non-integer lr ratio (configs[4] style)
+    (256, 24, 40, 12, 20, 192, 320, 12, True, "c8", torch.float16),
+    (512, 17, 20, 9, 10, 136, 160, 19, False, "c8", torch.float32),         # Cityscapes PSPNet: eight quarters
+    (64, 20, 30, 10, 15, 20, 30, 12, True, "nhwc", torch.float16),          # one quarter with 16-bit inputs
+    (256, 24, 40, 12, 20, 192, 320, 19, False, "c8", torch.float16),
+    (256, 24, 40, 12, 20, 192, 320, 12, False, "c8", torch.float32),
+    (256, 24, 40, 12, 20, 192, 320, 12, True, "c8", torch.bfloat16),
+])
+def test_creff_warp_wide_and_16bit(dev, C, Hp, Wp, hp, wp, H, W, n_cls, logsm, layout, dtype):
+    """ops.creff_warp (MV resize + warp + CReFF + head) beyond the 64-channel fp32 case of the fused kernel -- BiSeNet C = 256, Cityscapes
+    PSPNet C = 512, fp16 / bf16 inputs, MVs at 8x the feature resolution, non-integer lr ratios -- against the oracle's MV resize -> warp ->
+    MyAttention -> head evaluated on the same (rounded) inputs.  These shapes run as a warp launch + the matrix-core CReFF kernel."""
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+    from oracle import cpu_ref
+
+    N = 2
+    g = np.random.Generator(np.random.PCG64(131))
+    m = synth.load_synth_weights(MyAttention(C, kW=7, kH=7), 9, attn_gain=0.35)
+    sd = {kk: v.clone() for kk, v in m.state_dict().items()}
+    refs = [rnd(140 + i, C, Hp, Wp).to(dtype) for i in range(N)]
+    lr = rnd(142, N, C, hp, wp).to(dtype)
+    s8 = H // Hp
+    mvq = torch.from_numpy((g.integers(-3 * s8, 3 * s8 + 1, (N, H, W, 2)) * 4).astype(np.int16))
+    mvq[1, : H // 2] = mvq[1, 0, 0]
+    hr_w = torch.cat([cpu_ref.warp_feature(refs[i][None].float(), cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq[i:i + 1]), Hp, Wp)) for i in range(N)])
+    want = cpu_ref.my_attention(sd, "", hr_w, lr.float(), 7, 7)
+    pa = PackedAttention(m, dev)
+    wf, bf = rnd(122, n_cls, C, scale=0.1), rnd(123, n_cls, scale=0.1)
+    refs_d = [r.permute(1, 2, 0).contiguous().to(dev) for r in refs]
+    lay = _lib.C8 if layout == "c8" else _lib.NHWC
+    p, logits = ops.creff_warp(refs_d, mvq.to(dev), lr.permute(0, 2, 3, 1).contiguous().to(dev), pa, (wf.to(dev), bf.to(dev)), logsm, 7, 7, p_layout=lay)
+    assert p.dtype == torch.float32 and logits.dtype == torch.float32
+    got = ops.from_c8(p, _lib.NCHW) if layout == "c8" else p.permute(0, 3, 1, 2)
+    tol = 2e-4
+    assert maxdiff(got, want) <= tol
+    lg = F.conv2d(want, wf[:, :, None, None], bf)
+    if logsm:
+        lg = F.log_softmax(lg, dim=1)
+    assert maxdiff(logits, lg) <= 3 * tol
+
+
 # ---------------------------------------------------------------------------------------------- warp + CReFF fused (C = 64)
 @pytest.mark.parametrize("Hp,Wp,hp,wp,n_cls,logsm,layout", [
     (40, 70, 20, 35, 12, True, "c8"),       # ragged vs the 16x16 tile
