@@ -769,12 +769,12 @@ def test_upsample2x_fast_path(dev, N, H, W, C):
 
 # ---------------------------------------------------------------------------------------------- ops.creff_warp at C = 128 .. 512, fp32 / 16-bit inputs
 @pytest.mark.parametrize("C,Hp,Wp,hp,wp,H,W,n_cls,logsm,layout,dtype", [
-    (128, 33, 47, 17, 24, 33, 47, 19, False, "c8", torch.float32),          # two quarters, identity MV resize, odd sizes
-    (256, 24, 40, 12, 20, 192, 320, 19, False, "c8", torch.float32),        # BiSeNet: four quarters, MVs at 8x the feature resolution
+    (128, 33, 47, 17, 24, 33, 47, 19, False, "c8", torch.float32),          # identity MV resize, odd sizes
+    (256, 24, 40, 12, 20, 192, 320, 19, False, "c8", torch.float32),        # BiSeNet: MVs at 8x the feature resolution
     (256, 21, 37, 10, 18, 168, 296, 19, False, "nhwc", torch.bfloat16),     # 16-bit inputs, non-integer lr ratio (configs[4] style)
     (256, 24, 40, 12, 20, 192, 320, 12, True, "c8", torch.float16),
-    (512, 17, 20, 9, 10, 136, 160, 19, False, "c8", torch.float32),         # Cityscapes PSPNet: eight quarters
-    (64, 20, 30, 10, 15, 20, 30, 12, True, "nhwc", torch.float16),          # one quarter with 16-bit inputs
+    (512, 17, 20, 9, 10, 136, 160, 19, False, "c8", torch.float32),         # Cityscapes PSPNet
+    (64, 20, 30, 10, 15, 20, 30, 12, True, "nhwc", torch.float16),          # 64 channels with 16-bit inputs (the fused kernel is fp32 only)
     (256, 24, 40, 12, 20, 192, 320, 19, False, "c8", torch.float16),
     (256, 24, 40, 12, 20, 192, 320, 12, False, "c8", torch.float32),
     (256, 24, 40, 12, 20, 192, 320, 12, True, "c8", torch.bfloat16),
