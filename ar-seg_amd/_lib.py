@@ -81,6 +81,7 @@ PROTOTYPES = {
     "arseg_head16_fwd": (c_int, [_P, c_int, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_cast_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, _STREAM]),
     "arseg_warp_mvq16_fwd": (c_int, [_P, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_warp_mvq16_shared_fwd": (c_int, [_P, c_int64, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_blockrow_fwd": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),

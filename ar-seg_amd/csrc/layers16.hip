@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void cast_to16_kernel(const float *__restrict_
 // move 8-channel vectors; the blend is fp32 on the converted taps.
 template <bool BF>
 __global__ __launch_bounds__(256) void warp_mvq16_kernel(const uint16_t *__restrict__ feat, const int16_t *__restrict__ mv, float *__restrict__ out, int N, int C,
-                                                         int Hp, int Wp, int H, int W) {
+                                                         int Hp, int Wp, int H, int W, long long feat_n_stride) {
     __shared__ int s_off[4][64];
     __shared__ float s_w[4][64];
     const int tid = threadIdx.x, y = blockIdx.y, n = blockIdx.z, xb = blockIdx.x * 64;
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void warp_mvq16_kernel(const uint16_t *__restr
     }
     __syncthreads();
     const int sub = tid & 7;
-    const uint16_t *img = feat + (size_t)n * Hp * Wp * C;
+    const uint16_t *img = feat + (size_t)n * feat_n_stride;       // (stride 0: the frames of a GOP sample one keyframe feature)
     const int hw = Hp * Wp;
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -520,12 +520,18 @@ extern "C" int arseg_cast_fwd(const void *in, int in_dtype, void *out, int out_d
 
 extern "C" int arseg_warp_mvq16_fwd(const void *feature, int dtype, const int16_t *mv_q, float *out_c8, int N, int C, int Hp, int Wp, int H, int W,
                                     arseg_stream_t stream) {
+    return arseg_warp_mvq16_shared_fwd(feature, (long long)Hp * Wp * C, dtype, mv_q, out_c8, N, C, Hp, Wp, H, W, stream);
+}
+
+extern "C" int arseg_warp_mvq16_shared_fwd(const void *feature, long long feat_n_stride, int dtype, const int16_t *mv_q, float *out_c8, int N, int C,
+                                           int Hp, int Wp, int H, int W, arseg_stream_t stream) {
+    if (feat_n_stride < 0 || (feat_n_stride & 7)) return ARSEG_EINVAL;
     ARSEG_CHECK_PTR(feature); ARSEG_CHECK_PTR(mv_q); ARSEG_CHECK_PTR(out_c8);
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp);
     if ((C & 7) || !ARSEG_ALIGNED16(feature) || !ARSEG_ALIGNED16(out_c8)) return ARSEG_EINVAL;
     if (Hp > 65535 || N > 65535) return ARSEG_EUNSUPPORTED;
     const dim3 grid(arseg_cdiv(Wp, 64), Hp, N);
-    DISPATCH_BF(dtype, hipLaunchKernelGGL(warp_mvq16_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)feature, mv_q, out_c8, N, C, Hp, Wp, H, W),
-                hipLaunchKernelGGL(warp_mvq16_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)feature, mv_q, out_c8, N, C, Hp, Wp, H, W));
+    DISPATCH_BF(dtype, hipLaunchKernelGGL(warp_mvq16_kernel<true>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)feature, mv_q, out_c8, N, C, Hp, Wp, H, W, feat_n_stride),
+                hipLaunchKernelGGL(warp_mvq16_kernel<false>, grid, dim3(256), 0, arseg_stream(stream), (const uint16_t *)feature, mv_q, out_c8, N, C, Hp, Wp, H, W, feat_n_stride));
     return arseg_launch_status();
 }

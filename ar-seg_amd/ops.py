@@ -447,9 +447,15 @@ def creff_warp(refs_nhwc, mv_q: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=
         Hp, Wp, _ = refs_nhwc[0].shape
         _, H, W, _ = mv_q.shape
         ref_c8 = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=lr_nhwc.device)
-        for b in range(B):
-            _launch("warp_mvq", _lib.load().arseg_warp_mvq16_fwd, _ptr(refs_nhwc[b].contiguous()), dt, _ptr(mv_q[b:b + 1]), _ptr(ref_c8[b:b + 1]), 1, C, Hp, Wp,
-                    H, W, _stream(), nbytes=2 * C * Hp * Wp + 4 * C * Hp * Wp + 4 * H * W)
+        refs16 = [r.contiguous() for r in refs_nhwc]
+        if B * C * Hp * Wp * 4 < (1 << 31) and all(r.data_ptr() == refs16[0].data_ptr() for r in refs16):
+            # the non-keyframes of one GOP share the keyframe feature: one launch for the batch (feature stride 0) instead of one per frame
+            _launch("warp_mvq", _lib.load().arseg_warp_mvq16_shared_fwd, _ptr(refs16[0]), 0, dt, _ptr(mv_q), _ptr(ref_c8), B, C, Hp, Wp,
+                    H, W, _stream(), nbytes=B * (2 * C * Hp * Wp + 4 * C * Hp * Wp + 4 * H * W))
+        else:
+            for b in range(B):
+                _launch("warp_mvq", _lib.load().arseg_warp_mvq16_fwd, _ptr(refs16[b]), dt, _ptr(mv_q[b:b + 1]), _ptr(ref_c8[b:b + 1]), 1, C, Hp, Wp,
+                        H, W, _stream(), nbytes=2 * C * Hp * Wp + 4 * C * Hp * Wp + 4 * H * W)
         p_c8, logits = creff(ref_c8, cast(lr_nhwc, torch.float32), attn, head, log_softmax, kH, kW)
         return (p_c8 if p_layout == _lib.C8 else from_c8(p_c8, _lib.NHWC)), logits
     _need_gpu(lr_nhwc, *refs_nhwc)

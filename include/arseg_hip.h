@@ -359,6 +359,10 @@ int arseg_head16_fwd(const void *p, int p_ld, int dtype, const float *wf, const 
 int arseg_cast_fwd(const void *in, int in_dtype, void *out, int out_dtype, long long count, arseg_stream_t stream);
 int arseg_warp_mvq16_fwd(const void *feature, int dtype, const int16_t *mv_q, float *out_c8, int N, int C, int Hp, int Wp, int H,
                          int W, arseg_stream_t stream);
+/* The same with an explicit element stride between the frames' features: 0 = all N frames (the non-keyframes of one GOP) sample the same
+ * keyframe feature -- one launch per GOP instead of one per frame. */
+int arseg_warp_mvq16_shared_fwd(const void *feature, long long feat_n_stride, int dtype, const int16_t *mv_q, float *out_c8, int N, int C,
+                                int Hp, int Wp, int H, int W, arseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluator tail                                                       evaluation.py:201-213

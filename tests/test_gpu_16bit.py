@@ -166,6 +166,18 @@ def test_warp_mvq16(dev, dtype):
                                   ctypes.c_void_p(out.data_ptr()), 1, C, Hp, Wp, H, W, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert st == 0
     assert maxdiff(ops.from_c8(out, _lib.NCHW), want) <= 1e-5
+    # one launch for the non-keyframes of a GOP (feature stride 0: every frame samples the same keyframe feature) == one launch per frame
+    B = 3
+    mvb = torch.from_numpy((g.integers(-12, 13, (B, H, W, 2)) * 4).astype(np.int16)).to(dev)
+    outb = torch.empty((B, C // 8, Hp, Wp, 8), dtype=torch.float32, device=dev)
+    st = lib.arseg_warp_mvq16_shared_fwd(ctypes.c_void_p(feat_d.data_ptr()), 0, ops._DT16[dtype], ctypes.c_void_p(mvb.data_ptr()),
+                                         ctypes.c_void_p(outb.data_ptr()), B, C, Hp, Wp, H, W, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0
+    for b in range(B):
+        one = torch.empty((1, C // 8, Hp, Wp, 8), dtype=torch.float32, device=dev)
+        assert lib.arseg_warp_mvq16_fwd(ctypes.c_void_p(feat_d.data_ptr()), ops._DT16[dtype], ctypes.c_void_p(mvb[b:b + 1].data_ptr()),
+                                        ctypes.c_void_p(one.data_ptr()), 1, C, Hp, Wp, H, W, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        assert torch.equal(outb[b:b + 1], one)
 
 
 def _bise16(manifest, dev, fuse, dtype):
