@@ -848,7 +848,14 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
                         plan, best_t = (cfg, sk), t
             _conv_plans[key] = plan = plan or (0, 0)
         d.tile_cfg, d.split_k = plan
-    _launch("conv2d", lib.arseg_conv2d16_fwd, *args(), flops=2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin)
+    global _layer_tag
+    outer_tag, flops16 = _layer_tag, 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
+    if _profile is not None and outer_tag is None:      # per-layer table (profile.layers())
+        _layer_tag = (N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, bool(up2), "16-bit " + str((d.tile_cfg, d.split_k)), flops16)
+    try:
+        _launch("conv2d", lib.arseg_conv2d16_fwd, *args(), flops=flops16)
+    finally:
+        _layer_tag = outer_tag
     return out
 
 
