@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARSEG_HIP_LIB", os.path.join(_HERE, "lib", "libarseg_hip.so"))   # env override: kernel experiments
 
-ABI_VERSION = 3          # ARSEG_ABI_VERSION of include/arseg_hip.h
+ABI_VERSION = 4          # ARSEG_ABI_VERSION of include/arseg_hip.h
 ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 NCHW, NHWC, C8 = 0, 1, 2
@@ -58,8 +58,11 @@ PROTOTYPES = {
     "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
     "arseg_conv2d_find_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
+    "arseg_split_rows_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _STREAM]),
+    "arseg_gemm_x3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int, c_float, c_int, _STREAM]),
     "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
     "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
+    "arseg_wino43_input_split_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _STREAM]),
     "arseg_upconv3x3_tap_gather_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
     "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),

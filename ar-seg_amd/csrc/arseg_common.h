@@ -70,6 +70,13 @@ __device__ __forceinline__ void arseg_split_f16(const f32x4 v, unsigned &h01, un
     l01 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
     l23 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l2, l3));
 }
+// two values: (a, b) -> packed hi halves, packed lo halves (4 instructions)
+__device__ __forceinline__ void arseg_split_f16_pair(float a, float b, unsigned &h, unsigned &l) {
+    float l0, l1;
+    asm("v_cvt_pkrtz_f16_f32 %0, %3, %4\n\tv_fma_mix_f32 %1, %0, -1.0, %3 op_sel_hi:[1,0,0]\n\tv_fma_mix_f32 %2, %0, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h), "=&v"(l0), "=&v"(l1) : "v"(a), "v"(b));
+    l = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(l0, l1));
+}
 #endif
 
 // Bilinear source coordinate exactly as ATen computes it for fp32 tensors

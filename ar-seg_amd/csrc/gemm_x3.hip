@@ -1,0 +1,299 @@
+// Batched GEMM on operands that are ALREADY split into fp16 (hi, lo) pairs in HBM (the f16x3 arithmetic of conv_igemm.hip:
+// a.b = a_hi.b_hi + a_hi.b_lo + a_lo.b_hi on v_mfma_f32_16x16x32_f16, fp32 accumulate).
+//
+//   C[b][m][n] = act(scale[n] * sum_k X[b][m][k] * W[b][n][k] + bias[n])
+//
+// Operand layout ("split rows", the LDS row layout of conv_igemm.hip's f16x3 back end moved to HBM): a row of K values is K/32
+// groups of 128 bytes, each = 32 hi halves then 32 lo halves.  The same 4 bytes per value as fp32, so a producer that writes its
+// output this way (arseg_wino43_input_fwd with split = 1, arseg_split_rows_fwd) costs the consumer nothing -- and the consumer no
+// longer stages through registers: there is no conversion left to do on the way into LDS.
+//
+// Why a second GEMM kernel.  conv_igemm_kernel register-stages its operands (global -> VGPR -> split -> ds_write), two barriers or
+// two register stages per 32-deep K step: MFMA pipe 25-38 % busy.  Here
+//   * operands go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction), no VGPRs, no VALU;
+//   * the LDS image is the linear image the DMA writes (8 rows x 128 B per instruction); bank conflicts of the fragment reads are
+//     removed by permuting the SOURCE 16-byte slots of a row (slot ^ ((row >> 1) & 7)) and applying the same XOR on the read: the
+//     four 16-lane groups of a ds_read_b128 then touch 16 distinct slots of the 256-byte bank row;
+//   * a 256 x 256 tile per workgroup of 8 waves (2 x 4; 128 x 64 per wave = 32 accumulator fragments), one 128-byte group per
+//     K step, double buffered (128 KiB): 96 MFMAs per wave and K step against 24 ds_read_b128, ONE barrier per K step;
+//   * D is computed transposed (weights as the MFMA's A operand) so that a lane holds 4 consecutive output channels: 16-byte stores.
+#include "arseg_common.h"
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct GX3Params {
+    const unsigned char *X, *W;
+    float *C;
+    const float *scale, *bias;
+    int M, N, K, ldc;
+    unsigned x_bytes, w_bytes;        // extent of one problem's operands (buffer descriptors)
+    long long x_bs, w_bs, c_bs;       // batch strides: bytes, bytes, floats
+    int tiles_m, tiles_n, batch;
+    int act;
+    float slope;
+};
+
+__device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ u32x4 make_rsrc(const void *base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    return u32x4{(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(a >> 32) & 0xffffu)),
+                 (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+}
+// LDS[lds_base + lane*16 .. +15] <- buffer[voff .. +15]
+__device__ __forceinline__ void dma16_buf(const u32x4 rsrc, unsigned voff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+
+// NWM x NWN waves; 16-row fragments per wave: WTM along M (activation rows), WTN along N (weight rows)
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params p) {
+    constexpr int NW = NWM * NWN, BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
+    constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
+    constexpr int XI = BM / (8 * NW), WI = BN / (8 * NW);  // DMA instructions per wave and K step (8 rows each)
+    static_assert(XI >= 1 && WI >= 1 && XI * 8 * NW == BM && WI * 8 * NW == BN, "tile rows must divide over the waves in 8-row pieces");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int per = p.tiles_m * p.tiles_n, nblk = per * p.batch;
+    int bid = blockIdx.x;
+    {
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int b = bid / per, rem = bid - b * per;
+    const int tile_m = rem / p.tiles_n, tile_n = rem - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const u32x4 x_rsrc = make_rsrc(p.X + (size_t)b * p.x_bs, p.x_bytes);
+    const u32x4 w_rsrc = make_rsrc(p.W + (size_t)b * p.w_bs, p.w_bytes);
+    const unsigned ld = (unsigned)p.K * 4u;
+
+    // DMA: lane (r8, pos) of instruction j fills LDS row wave*rows + 8j + r8, 16-byte position pos, with source slot pos ^ g(row)
+    const int r8 = lane >> 3, pos = lane & 7;
+    unsigned xsrc[XI], wsrc[WI];
+#pragma unroll
+    for (int j = 0; j < XI; ++j) {
+        const int row = wave * (BM / NW) + j * 8 + r8;
+        xsrc[j] = (unsigned)min(m0 + row, p.M - 1) * ld + (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+        const int row = wave * (BN / NW) + j * 8 + r8;
+        wsrc[j] = (unsigned)min(n0 + row, p.N - 1) * ld + (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+    }
+    const unsigned lds0 = lds_addr(smem);
+    auto issue_x = [&](int kt, int st) {
+        const unsigned kb = (unsigned)kt * 128u, base = lds0 + (unsigned)st * STAGE;
+#pragma unroll
+        for (int j = 0; j < XI; ++j) dma16_buf(x_rsrc, xsrc[j] + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
+    };
+    auto issue_w = [&](int kt, int st) {
+        const unsigned kb = (unsigned)kt * 128u, base = lds0 + (unsigned)st * STAGE;
+#pragma unroll
+        for (int j = 0; j < WI; ++j) dma16_buf(w_rsrc, wsrc[j] + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
+    };
+
+    // fragment reads: lane (i16, kq) reads row i16 of a 16-row fragment, source slot kq (hi) / 4 + kq (lo) -> position slot ^ (i16 >> 1)
+    const int i16 = lane & 15, kq = lane >> 4;
+    const unsigned xo = (unsigned)(wm * (BM / NWM) + i16) * 128u + (unsigned)((kq ^ (i16 >> 1)) << 4);
+    const unsigned wo = XB + (unsigned)(wn * (BN / NWN) + i16) * 128u + (unsigned)((kq ^ (i16 >> 1)) << 4);
+
+    f32x4 acc[WTM][WTN];
+#pragma unroll
+    for (int a = 0; a < WTM; ++a)
+#pragma unroll
+        for (int c = 0; c < WTN; ++c) acc[a][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int PRIO = (ABL & 4) ? 1 : 0;
+    constexpr bool NOREAD = (ABL & 2) != 0, NODMA = (ABL & 1) != 0;
+    constexpr int HM = WTM >= 4 ? WTM / 2 : WTM;         // activation fragments held at a time
+    auto mfmas = [&](int h, const h16x8 (&wh)[WTN], const h16x8 (&wl)[WTN], const h16x8 (&xh)[HM], const h16x8 (&xl)[HM]) {
+#pragma unroll
+        for (int a = 0; a < HM; ++a)
+#pragma unroll
+            for (int c = 0; c < WTN; ++c) acc[h * HM + a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[c], xh[a], acc[h * HM + a][c], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < HM; ++a)
+#pragma unroll
+            for (int c = 0; c < WTN; ++c) acc[h * HM + a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], xl[a], acc[h * HM + a][c], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < HM; ++a)
+#pragma unroll
+            for (int c = 0; c < WTN; ++c) acc[h * HM + a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[c], xh[a], acc[h * HM + a][c], 0, 0, 0);
+    };
+    h16x8 pwh[WTN], pwl[WTN], pxh[HM], pxl[HM];           // (ablation builds: fragments read once)
+    auto compute = [&](int st, int kt_next) {       // kt_next >= 0: the next K step's operands are requested into the other buffer on the way
+        const unsigned char *base = smem + st * STAGE;
+        if constexpr (NOREAD) {
+#pragma unroll
+            for (int h = 0; h < WTM / HM; ++h) {
+                if (kt_next >= 0) { if (h == 0) issue_x(kt_next, st ^ 1); else if (h == WTM / HM - 1) issue_w(kt_next, st ^ 1); }
+                mfmas(h, pwh, pwl, pxh, pxl);
+            }
+            return;
+        }
+        h16x8 wh[WTN], wl[WTN];
+#pragma unroll
+        for (int c = 0; c < WTN; ++c) {
+            wh[c] = *reinterpret_cast<const h16x8 *>(base + wo + c * 2048);
+            wl[c] = *reinterpret_cast<const h16x8 *>(base + (wo ^ 64u) + c * 2048);
+        }
+#pragma unroll
+        for (int h = 0; h < WTM / HM; ++h) {
+            h16x8 xh[HM], xl[HM];
+#pragma unroll
+            for (int a = 0; a < HM; ++a) {
+                xh[a] = *reinterpret_cast<const h16x8 *>(base + xo + (h * HM + a) * 2048);
+                xl[a] = *reinterpret_cast<const h16x8 *>(base + (xo ^ 64u) + (h * HM + a) * 2048);
+            }
+            // the DMA requests go out behind the fragment reads of a half, in front of its MFMAs: a request costs the issuing wave 60-180
+            // cycles during which the other waves of the SIMD own the matrix pipe
+            if (kt_next >= 0) {
+                if (h == 0) issue_x(kt_next, st ^ 1);
+                if (h == WTM / HM - 1) issue_w(kt_next, st ^ 1);
+            }
+            __builtin_amdgcn_s_setprio(PRIO);
+            mfmas(h, wh, wl, xh, xl);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    };
+
+    const int nk = p.K >> 5;
+    issue_x(0, 0);
+    issue_w(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if constexpr (NOREAD) {
+#pragma unroll
+        for (int c = 0; c < WTN; ++c) {
+            pwh[c] = *reinterpret_cast<const h16x8 *>(smem + wo + c * 2048);
+            pwl[c] = *reinterpret_cast<const h16x8 *>(smem + (wo ^ 64u) + c * 2048);
+        }
+#pragma unroll
+        for (int a = 0; a < HM; ++a) {
+            pxh[a] = *reinterpret_cast<const h16x8 *>(smem + xo + a * 2048);
+            pxl[a] = *reinterpret_cast<const h16x8 *>(smem + (xo ^ 64u) + a * 2048);
+        }
+    }
+#pragma unroll 1
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        // (the other buffer is free: everybody finished reading it before the last barrier)
+        compute(NOREAD ? 0 : cur, (kt + 1 < nk && !NODMA) ? kt + 1 : -1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue: D[n][m]: lane (i16, kq) of fragment (a, c) holds channels n..n+3 (n = 16c + 4kq) of row m = 16a + i16
+    float *__restrict__ C = p.C + (size_t)b * p.c_bs;
+    const bool prelu = p.act == ARSEG_ACT_PRELU, relu = p.act == ARSEG_ACT_RELU, sigm = p.act == ARSEG_ACT_SIGMOID;
+#pragma unroll
+    for (int c = 0; c < WTN; ++c) {
+        const int n = n0 + wn * (BN / NWN) + c * 16 + 4 * kq;
+        if (n >= p.N) continue;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (p.scale) sc = *reinterpret_cast<const f32x4 *>(p.scale + n);
+        if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
+#pragma unroll
+        for (int a = 0; a < WTM; ++a) {
+            const int m = m0 + wm * (BM / NWM) + a * 16 + i16;
+            if (m >= p.M) continue;
+            f32x4 v = acc[a][c] * sc + bi;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (relu) v[e] = fmaxf(v[e], 0.f);
+                else if (prelu) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
+                else if (sigm) v[e] = 1.0f / (1.0f + __expf(-v[e]));
+            }
+            *reinterpret_cast<f32x4 *>(C + (size_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
+// fp32 rows -> split rows (the operand layout above); 4 values per thread
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ in, long long in_ld, unsigned char *__restrict__ out, long long rows, int K, float mul) {
+    const int k4 = K >> 2;
+    const long long total = rows * k4;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long r = idx / k4;
+        const int c = (int)(idx - r * k4) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4 *>(in + r * in_ld + c);
+        v *= mul;
+        unsigned h01, h23, l01, l23;
+        arseg_split_f16(v, h01, h23, l01, l23);
+        unsigned char *o = out + r * (long long)K * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+        *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
+    }
+}
+
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0>
+int launch_x3(GX3Params &p, hipStream_t hs) {
+    constexpr int BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
+    p.tiles_m = arseg_cdiv(p.M, BM); p.tiles_n = arseg_cdiv(p.N, BN);
+    if ((long long)p.tiles_m * p.tiles_n * p.batch >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
+    const size_t smem = (size_t)2 * (BM + BN) * 128;
+    static ArsegSmemAttr attr;
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL>), smem)) return e;
+    hipLaunchKernelGGL((gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL>), dim3(p.tiles_m * p.tiles_n * p.batch), dim3(64 * NWM * NWN), smem, hs, p);
+    return arseg_launch_status();
+}
+
+template <int ABL>
+int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
+    switch (cfg) {
+        case 0: return launch_x3<2, 4, 8, 4, ABL>(p, hs);      // 256 x 256,  8 waves
+        case 1: return launch_x3<4, 4, 4, 4, ABL>(p, hs);      // 256 x 256, 16 waves
+        case 2: return launch_x3<2, 4, 4, 4, ABL>(p, hs);      // 128 x 256,  8 waves
+        case 3: return launch_x3<2, 4, 4, 2, ABL>(p, hs);      // 128 x 128,  8 waves
+        case 4: return launch_x3<4, 4, 4, 2, ABL>(p, hs);      // 256 x 128, 16 waves
+        case 5: return launch_x3<4, 4, 2, 4, ABL>(p, hs);      // 128 x 256, 16 waves
+        default: return ARSEG_EINVAL;
+    }
+}
+
+}  // namespace
+
+extern "C" int arseg_split_rows_fwd(const float *in, long long in_ld, void *out, long long rows, int K, float mul, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out);
+    if (rows <= 0 || K <= 0 || (K & 31) || in_ld < K || (in_ld & 3) || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    long long blocks = (rows * (K >> 2) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, arseg_stream(stream), in, in_ld, reinterpret_cast<unsigned char *>(out), rows, K, mul);
+    return arseg_launch_status();
+}
+
+extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
+                                 long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
+                                 const float *bias, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(x_split); ARSEG_CHECK_PTR(w_split); ARSEG_CHECK_PTR(out);
+    if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 3) || out_ld < N || (out_ld & 3) || batch <= 0) return ARSEG_EINVAL;
+    if (!ARSEG_ALIGNED16(x_split) || !ARSEG_ALIGNED16(w_split) || !ARSEG_ALIGNED16(out) || (x_batch_stride & 15) || (w_batch_stride & 15) || (out_batch_stride & 3))
+        return ARSEG_EINVAL;
+    if ((scale && !ARSEG_ALIGNED16(scale)) || (bias && !ARSEG_ALIGNED16(bias))) return ARSEG_EINVAL;
+    if ((long long)M * K * 4 >= (1ll << 32) || (long long)N * K * 4 >= (1ll << 32)) return ARSEG_EUNSUPPORTED;      // 32-bit buffer offsets
+    GX3Params p;
+    p.X = reinterpret_cast<const unsigned char *>(x_split); p.W = reinterpret_cast<const unsigned char *>(w_split); p.C = out;
+    p.scale = scale; p.bias = bias; p.M = M; p.N = N; p.K = K; p.ldc = out_ld;
+    p.x_bytes = (unsigned)((long long)M * K * 4); p.w_bytes = (unsigned)((long long)N * K * 4);
+    p.x_bs = batch > 1 ? x_batch_stride : 0; p.w_bs = batch > 1 ? w_batch_stride : 0; p.c_bs = batch > 1 ? out_batch_stride : 0;
+    p.batch = batch; p.act = act; p.slope = prelu_slope;
+    hipStream_t hs = arseg_stream(stream);
+    const int abl = tile_cfg >> 3;
+    tile_cfg &= 7;
+    switch (abl) {
+        case 0: return launch_cfg<0>(p, tile_cfg, hs);
+        case 1: return launch_cfg<1>(p, tile_cfg, hs);
+        case 2: return launch_cfg<2>(p, tile_cfg, hs);
+        case 3: return launch_cfg<3>(p, tile_cfg, hs);
+        case 4: return launch_cfg<4>(p, tile_cfg, hs);
+        default: return ARSEG_EINVAL;
+    }
+}

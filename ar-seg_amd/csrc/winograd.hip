@@ -56,12 +56,31 @@ __device__ __forceinline__ void tile_origin(const WinoGeom &g, int t, int &n, in
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+// One transformed value (pair) of frequency k, tile t, channel c.  SPLIT: V is written in the "split rows" operand format of
+// arseg_gemm_x3_fwd (csrc/gemm_x3.hip: per 32 channels 32 hi halves then 32 lo halves, the same 4 bytes per value) so that the batched
+// GEMM can stage it by LDS-DMA; the running |V| maximum feeds the operand range word (the GEMM no longer sees fp32 values to watch).
+template <bool SPLIT, typename F>
+__device__ __forceinline__ void put_v(float *__restrict__ V, size_t row, int C, int c, const F v, float &vmax) {
+    if constexpr (SPLIT) {
+        static_assert(sizeof(F) == 8, "split rows are written two channels at a time");
+        unsigned h, l;
+        arseg_split_f16_pair(v[0], v[1], h, l);
+        vmax = fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1])));
+        unsigned char *o = reinterpret_cast<unsigned char *>(V) + (row * C) * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<unsigned *>(o) = h;
+        *reinterpret_cast<unsigned *>(o + 64) = l;
+    } else {
+        *reinterpret_cast<F *>(V + row * C + c) = v;
+    }
+}
+
 // F = float (any C) or f32x2 (C even, 8-byte aligned rows): channels per thread
-template <typename F>
+template <typename F, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
-                                                           WinoGeom g, float vscale) {
+                                                           WinoGeom g, float vscale, unsigned *range_flag, float range_limit) {
     constexpr int VW = sizeof(F) / sizeof(float);
     const int Cv = C / VW, total = g.T * Cv;
+    float vmax = 0.f;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int t = idx / Cv, c = (idx - t * Cv) * VW;
         int n, y0, x0;
@@ -93,9 +112,10 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
             F r[6];
             bt6(tmp[i], r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j] * vscale;
+            for (int j = 0; j < 6; ++j) put_v<SPLIT>(V, (size_t)(i * 6 + j) * g.T + t, C, c, F(r[j] * vscale), vmax);
         }
     }
+    if (SPLIT && range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
 // Input transform with the x2 bilinear upsample of PSPUpsample (F.upsample default = align_corners=False,
@@ -103,11 +123,12 @@ __global__ __launch_bounds__(256) void wino43_input_kernel(const float *__restri
 // materialised) upsampled image is built from a 4x4 low-resolution neighbourhood.  With scale exactly 2 the source
 // offsets are the constants 0.25 / 0.75, and clamping the neighbourhood loads to the image edge reproduces ATen's
 // border handling exactly (src < 0 -> 0; i1 = min(i0+1, h-1)).  Dilation 1 only.
-template <typename F>
+template <typename F, bool SPLIT = false>
 __global__ __launch_bounds__(256) void wino43_input_up2_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ V, int C,
-                                                               WinoGeom g, float vscale) {
+                                                               WinoGeom g, float vscale, unsigned *range_flag, float range_limit) {
     constexpr int VW = sizeof(F) / sizeof(float);
     const int Cv = C / VW, total = g.T * Cv, h = g.H >> 1, w = g.W >> 1;
+    float vmax = 0.f;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
         const int t = idx / Cv, c = (idx - t * Cv) * VW;
         int n, y0, x0;
@@ -157,9 +178,10 @@ __global__ __launch_bounds__(256) void wino43_input_up2_kernel(const float *__re
             F r[6];
             bt6(tmp[i], r);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) *reinterpret_cast<F *>(V + ((size_t)(i * 6 + j) * g.T + t) * C + c) = r[j] * vscale;
+            for (int j = 0; j < 6; ++j) put_v<SPLIT>(V, (size_t)(i * 6 + j) * g.T + t, C, c, F(r[j] * vscale), vmax);
         }
     }
+    if (SPLIT && range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
 __device__ __forceinline__ float wino_act(float v, int act, float slope) {
@@ -234,8 +256,8 @@ extern "C" long long arseg_wino43_tiles(int N, int H, int W, int dil) {
     return t;
 }
 
-extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
-                                      float v_scale, arseg_stream_t stream) {
+static int wino43_input(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x, float v_scale, bool split,
+                        void *range_flag, float range_limit, arseg_stream_t stream) {
     if (!(v_scale > 0.0f)) return ARSEG_EINVAL;
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(V); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(dil);
     if (in_ld < C) return ARSEG_EINVAL;
@@ -244,16 +266,35 @@ extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int 
     if (T * C >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const WinoGeom g = make_geom(N, H, W, dil);
     const bool vec2 = !(C & 1) && !(in_ld & 1) && !(reinterpret_cast<uintptr_t>(in) & 7) && !(reinterpret_cast<uintptr_t>(V) & 7);
+    unsigned *rf = reinterpret_cast<unsigned *>(range_flag);
+    const float rl = range_limit > 0.0f ? range_limit : 65504.0f;
+    hipStream_t hs = arseg_stream(stream);
+    if (split) {
+        if (!vec2 || (C & 31) || !ARSEG_ALIGNED16(V) || (reinterpret_cast<uintptr_t>(range_flag) & 3)) return ARSEG_EINVAL;
+        if (upsample2x) hipLaunchKernelGGL((wino43_input_up2_kernel<f32x2, true>), dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
+        else hipLaunchKernelGGL((wino43_input_kernel<f32x2, true>), dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
+        return arseg_launch_status();
+    }
     if (upsample2x) {
-        if (vec2) hipLaunchKernelGGL(wino43_input_up2_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
-        else hipLaunchKernelGGL(wino43_input_up2_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
+        if (vec2) hipLaunchKernelGGL((wino43_input_up2_kernel<f32x2>), dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
+        else hipLaunchKernelGGL((wino43_input_up2_kernel<float>), dim3(grid_for((long long)g.T * C)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
         return arseg_launch_status();
     }
     if (vec2)
-        hipLaunchKernelGGL(wino43_input_kernel<f32x2>, dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
+        hipLaunchKernelGGL((wino43_input_kernel<f32x2>), dim3(grid_for((long long)g.T * C / 2)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
     else
-        hipLaunchKernelGGL(wino43_input_kernel<float>, dim3(grid_for((long long)g.T * C)), dim3(256), 0, arseg_stream(stream), in, in_ld, V, C, g, v_scale);
+        hipLaunchKernelGGL((wino43_input_kernel<float>), dim3(grid_for((long long)g.T * C)), dim3(256), 0, hs, in, in_ld, V, C, g, v_scale, rf, rl);
     return arseg_launch_status();
+}
+
+extern "C" int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x,
+                                      float v_scale, arseg_stream_t stream) {
+    return wino43_input(in, in_ld, V, N, H, W, C, dil, upsample2x, v_scale, false, nullptr, 0.0f, stream);
+}
+
+extern "C" int arseg_wino43_input_split_fwd(const float *in, int in_ld, void *V_split, int N, int H, int W, int C, int dil, int upsample2x,
+                                            float v_scale, void *range_flag, float range_limit, arseg_stream_t stream) {
+    return wino43_input(in, in_ld, reinterpret_cast<float *>(V_split), N, H, W, C, dil, upsample2x, v_scale, true, range_flag, range_limit, stream);
 }
 
 extern "C" int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,

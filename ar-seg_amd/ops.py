@@ -37,6 +37,7 @@ class Config:
     conv_find        [ARSEG_CONV_FIND = native | python]        who times the candidate plans: arseg_conv2d_find or the host loop
     conv_winograd    [ARSEG_CONV_WINOGRAD = 1 | 0]              let the tuner consider Winograd F(4x4,3x3)
     conv_up2_taps    [ARSEG_CONV_UP2_TAPS = 1 | 0]              let the tuner consider the tap decomposition for convs after a x2 upsample
+    conv_gemm_x3     [ARSEG_CONV_GEMM_X3 = 1 | 0]               let the tuner consider the LDS-DMA GEMM on pre-split operands (csrc/gemm_x3.hip)
     conv_range_guard [ARSEG_CONV_RANGE_GUARD = device | host | 0]   operand range of the f16x3 back end: sticky device word read by
                      ops.range_tripped() (default) / amax + host sync per conv with an immediate fp32 fallback / off
     conv_plan_file   [ARSEG_CONV_PLAN_FILE = <json>]            persist the tuned plans
@@ -49,6 +50,7 @@ class Config:
     conv_find: str = "native"
     conv_winograd: bool = True
     conv_up2_taps: bool = True
+    conv_gemm_x3: bool = True
     conv_range_guard: str = "device"
     conv_plan_file: Optional[str] = None
     creff_impl: str = ""
@@ -60,7 +62,7 @@ class Config:
         e = os.environ.get
         return cls(conv_math=e("ARSEG_CONV_MATH", "f16x3"), conv_autotune=e("ARSEG_CONV_AUTOTUNE", "1") != "0",
                    conv_find=e("ARSEG_CONV_FIND", "native"), conv_winograd=e("ARSEG_CONV_WINOGRAD", "1") != "0",
-                   conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0",
+                   conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0", conv_gemm_x3=e("ARSEG_CONV_GEMM_X3", "1") != "0",
                    conv_range_guard={"1": "host", "host": "host", "0": "off", "off": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), "device"),
                    conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=int(e("ARSEG_CREFF_TY", "0") or 0),
                    lr_subbatch=int(e("ARSEG_LR_SUBBATCH", "0") or 0))
@@ -874,7 +876,9 @@ def _time(fn, reps=6):
 
 
 def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
-    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs on the MFMA kernel -> output transform.
+    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs -> output transform.  The GEMMs run either on the
+    implicit-GEMM kernel in batched 1x1 mode (plan = its tile_cfg) or, with the transformed activations written as split rows, on the
+    LDS-DMA kernel of csrc/gemm_x3.hip (plan = 100 + its tile_cfg); whichever was faster when the shape was first seen.
     N,H,W: conv input size; with up2 ``x`` is the half-resolution tensor the input transform upsamples on the fly."""
     lib = _lib.load()
     Cin, Cout, dil = pc.cin_pad, pc.cout, pc.dil
@@ -885,7 +889,6 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     # under f16x3 the transformed activations are stored scaled by 2^-4 (exact; undone in the output transform): B^T d B amplifies by up to
     # 100, and unscaled the split-fp16 operand range would be left for |x| >~ 1.3e3
     vs = 2.0 ** -4 if _math == _lib.MATH_F16X3 else 1.0
-    la("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs, _stream())
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.in_ld = 1, T, 1, Cin, Cin
     d.Cout, d.out_ld, d.res_ld = Cout, Cout, Cout
@@ -895,19 +898,35 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     d.math = math = _math
     _arm_range_watch(d, x.device)          # the batched GEMM watches the transformed activations it multiplies
     u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math != _lib.MATH_F32 else (pc.wino_u, pc.scale)
+    x3_ok = _GEMM_X3 and math == _lib.MATH_F16X3 and Cin % 32 == 0 and Cout % 4 == 0
     key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
     plan = _conv_plans.get(key)
+    if plan is not None and plan >= 100 and not x3_ok:
+        plan = None
+
+    def transform(split, la_):
+        if split:      # the transform is the last place that sees the GEMM's fp32 operands: it carries the range watch
+            la_("wino_input", lib.arseg_wino43_input_split_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs,
+                ctypes.c_void_p(d.range_flag), 65504.0, _stream())
+        else:
+            la_("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs, _stream())
 
     def gemm(cfg, rec):
-        d.tile_cfg, d.split_k = cfg, 1
-        args = (ctypes.byref(d), _ptr(V), _ptr(u_dev), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
-        if rec:
-            _launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=2 * 36 * T * Cin * Cout)
+        if cfg >= 100:
+            fn, args = lib.arseg_gemm_x3_fwd, (_ptr(V), _ptr(u_dev), _ptr(M), T, Cout, Cin, Cout, 36, T * Cin * 4, Cout * Cin * 4, T * Cout,
+                                               _ptr(None), _ptr(None), _lib.ACT_NONE, 0.0, cfg - 100, _stream())
         else:
-            check(lib.arseg_conv2d_fwd(*args), "conv2d(batched)")
+            d.tile_cfg, d.split_k = cfg, 1
+            fn, args = lib.arseg_conv2d_fwd, (ctypes.byref(d), _ptr(V), _ptr(u_dev), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
+        if rec:
+            _launch("conv2d", fn, *args, flops=2 * 36 * T * Cin * Cout)
+        else:
+            check(fn(*args), "conv2d(batched)")
 
     if plan is None:
+        quiet = lambda name, fn, *a, **k: check(fn(*a), name)      # noqa: E731
         best, best_t = 0, float("inf")
+        transform(False, quiet)
         for cfg in (0, 5, 6, 7, 8, 9, 10, 11, 12) + ((17, 18, 19) if math == _lib.MATH_F16X3 else ()):
             if cfg in (5, 8, 9, 12, 17, 18, 19) and Cout <= 64:
                 continue
@@ -916,13 +935,21 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
             t = _time(lambda: gemm(cfg, False))
             if t < best_t:
                 best, best_t = cfg, t
+        if x3_ok:
+            transform(True, quiet)
+            for cfg in range(100, 106):
+                t = _time(lambda: gemm(cfg, False))
+                if t < best_t:
+                    best, best_t = cfg, t
         plan = _conv_plans[key] = best
+    transform(plan >= 100, la)
     gemm(plan, record)
     la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual),
        _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, 1.0 / vs, _stream())
 
 
 _UP2_TAPS = config.conv_up2_taps
+_GEMM_X3 = config.conv_gemm_x3
 
 
 def _conv_up2_taps(x_low, pc, out, record=True):
@@ -1174,4 +1201,6 @@ def _apply_config():
     _AUTOTUNE, _math = config.conv_autotune, _MATH_NAMES[config.conv_math]
     _RANGE_MODE = config.conv_range_guard if config.conv_range_guard in ("device", "host", "off") else "device"
     _RANGE_GUARD = _RANGE_MODE == "host"
+    global _GEMM_X3
     _NATIVE_FIND, _WINOGRAD, _UP2_TAPS = config.conv_find != "python", config.conv_winograd, config.conv_up2_taps
+    _GEMM_X3 = config.conv_gemm_x3

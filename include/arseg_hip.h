@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ARSEG_ABI_VERSION 3
+#define ARSEG_ABI_VERSION 4
 
 enum arseg_status {
     ARSEG_OK = 0,
@@ -232,9 +232,26 @@ long long arseg_wino43_tiles(int N, int H, int W, int dil);
  * activations (up to 100x, typically ~10x the input) otherwise leave the split-fp16 range for |x| >~ 1.3e3.  1.0f = no scaling. */
 int arseg_wino43_input_fwd(const float *in, int in_ld, float *V, int N, int H, int W, int C, int dil, int upsample2x, float v_scale,
                            arseg_stream_t stream);
+/* The same transform with V written in the split-row operand format of arseg_gemm_x3_fwd (C % 32 == 0, V_split 16-byte aligned, the
+ * same T*C*4 bytes per frequency): the 36 GEMMs then run as ONE arseg_gemm_x3_fwd(V_split, U_f16x3, M, T, Cout, C, ..., batch = 36).
+ * range_flag / range_limit: as in arseg_conv_desc -- the transform is where the fp32 operands of that GEMM are last seen. */
+int arseg_wino43_input_split_fwd(const float *in, int in_ld, void *V_split, int N, int H, int W, int C, int dil, int upsample2x,
+                                 float v_scale, void *range_flag, float range_limit, arseg_stream_t stream);
 int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bias, const float *residual, int res_ld, float *out,
                             int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale,
                             arseg_stream_t stream);
+
+/* Batched GEMM on operands that are already split into fp16 (hi, lo) pairs ("split rows": a row of K values, K % 32 == 0, is K/32
+ * groups of 128 bytes = 32 hi halves then 32 lo halves; the f16x3 weight format of arseg_split_weight_f16x3_host, now also for the
+ * activations):   out[b][m][n] = act(scale[n] * sum_k x[b][m][k] * w[b][n][k] + bias[n])       (scale / bias may be NULL)
+ * x_split [batch][M][K], w_split [batch][N][K] in split rows (batch strides in BYTES, multiples of 16), out fp32 [batch][M][out_ld]
+ * (stride in floats), N % 4 == 0.  Operands reach LDS by LDS-DMA, no register staging (csrc/gemm_x3.hip).  tile_cfg 0..3 = 256x256,
+ * 128x256, 256x128, 128x128 (M x N per workgroup).  The same fp32-grade arithmetic as ARSEG_MATH_F16X3 (three fp16 MFMAs per product).
+ * arseg_split_rows_fwd converts fp32 rows [rows][in_ld] (times `mul`, a power of two keeps it exact) to split rows [rows][K]. */
+int arseg_split_rows_fwd(const float *in, long long in_ld, void *out_split, long long rows, int K, float mul, arseg_stream_t stream);
+int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
+                      long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
+                      const float *bias, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream);
 
 /* conv3x3 (pad 1, stride 1) of a x2 bilinear (align_corners=False) upsample -- PSPUpsample, /root/reference/model/pspnet.py:43-46 --
  * by tap decomposition: since a 1x1 conv commutes with a per-channel resize, conv3x3(Up(x)) = sum_t shift_t(Up(W_t x)).  The caller

@@ -495,6 +495,79 @@ def test_conv2d_winograd(dev, N, H, W, Cin, Cout, dil, act, use_res, conv_math):
     assert maxdiff(direct, out) <= 2e-4
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,dil,up2", [(2, 19, 26, 64, 64, 1, False), (1, 32, 64, 128, 96, 2, False), (1, 17, 33, 256, 36, 4, False),
+                                                    (1, 40, 72, 512, 512, 1, False), (2, 18, 28, 64, 128, 1, True)])
+def test_conv2d_winograd_gemm_x3(dev, N, H, W, Cin, Cout, dil, up2):
+    """The Winograd route with its 36 GEMMs on the LDS-DMA kernel (split-row transform + arseg_gemm_x3_fwd, every tile_cfg) and the same
+    route on the implicit-GEMM kernel against F.conv2d (both hold the Winograd tolerance; the x3 tile shapes agree with each other)."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    g = np.random.Generator(np.random.PCG64(177))
+    h, w_ = (H // 2, W // 2) if up2 else (H, W)
+    x = rnd(170, N, Cin, h, w_)
+    w = rnd(171, Cout, Cin, 3, 3, scale=float(np.sqrt(2.0 / (Cin * 9))))
+    bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(172, Cout, scale=0.1), rnd(173, Cout, scale=0.1),
+          t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    pc = PackedConv(w, None, bn, 1, dil, dil, _lib.ACT_PRELU, 0.2, dev)
+    xin = F.interpolate(x, scale_factor=2.0, mode="bilinear", align_corners=False) if up2 else x
+    want = _conv_ref(xin, w, None, bn, 1, dil, dil, "prelu", 0.2, None)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    T = _lib.load().arseg_wino43_tiles(N, H, W, dil)
+    key = ("wino_gemm", dev.index, T, pc.cin_pad, Cout, _lib.MATH_F16X3)
+    prev_math = ops.set_conv_math("f16x3")
+    saved = ops._conv_plans.get(key)
+    try:
+        outs = {}
+        for plan in (7, 100, 101, 102, 103, 104, 105):
+            ops._conv_plans[key] = plan
+            out = torch.full((N, H, W, Cout), float("nan"), device=dev)
+            ops._conv_wino(xd, pc, None, out, N, H, W, up2=up2)
+            outs[plan] = out.permute(0, 3, 1, 2).cpu()
+            assert maxdiff(outs[plan], want) <= 2e-4, plan
+        for plan in range(100, 106):
+            assert maxdiff(outs[plan], outs[100]) <= 1e-6                # every tile shape adds the K steps in the same order
+    finally:
+        ops.set_conv_math(prev_math)
+        if saved is None:
+            ops._conv_plans.pop(key, None)
+        else:
+            ops._conv_plans[key] = saved
+
+
+@pytest.mark.parametrize("B,M,K,N", [(1, 1, 32, 4), (3, 300, 96, 36), (2, 257, 64, 260), (1, 1000, 256, 512), (36, 130, 128, 64)])
+def test_gemm_x3(dev, B, M, K, N):
+    """arseg_split_rows_fwd + arseg_gemm_x3_fwd (every tile_cfg; ragged M and N tails, single-step K, scale / bias / activation epilogue)
+    against an fp64 matmul: fp32-grade results from three fp16 products."""
+    import ctypes
+
+    from arseg_amd import _lib
+
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)      # noqa: E731
+    g = np.random.Generator(np.random.PCG64(300 + M))
+    x = torch.from_numpy((g.standard_normal((B, M, K)) * np.exp(g.standard_normal((B, M, 1)))).astype(np.float32)).to(dev)
+    w = rnd(301, B, N, K, scale=0.1).to(dev)
+    scale, bias = torch.from_numpy(g.uniform(0.5, 1.5, N).astype(np.float32)).to(dev), rnd(302, N).to(dev)
+    xs, ws = torch.empty_like(x), torch.empty_like(w)
+    _lib.check(lib.arseg_split_rows_fwd(P(x), K, P(xs), B * M, K, 1.0, st), "split")
+    _lib.check(lib.arseg_split_rows_fwd(P(w), K, P(ws), B * N, K, 1.0, st), "split")
+    # the split rows hold hi + lo = x to 22 bits
+    raw = xs.view(torch.float16).view(B, M, K // 32, 2, 32).float()
+    assert float((raw[:, :, :, 0] + raw[:, :, :, 1] - x.view(B, M, K // 32, 32)).abs().max()) <= 2.0 ** -21 * float(x.abs().max())
+    ref = torch.bmm(x.double(), w.double().transpose(1, 2))
+    for act, slope in ((_lib.ACT_NONE, 0.0), (_lib.ACT_PRELU, 0.25)):
+        want = ref if act == _lib.ACT_NONE else F.prelu(ref * scale.double() + bias.double(), torch.tensor([slope], dtype=torch.float64, device=dev))
+        for cfg in range(6):
+            out = torch.full((B, M, N), float("nan"), device=dev)
+            sb = (None, None) if act == _lib.ACT_NONE else (scale, bias)
+            _lib.check(lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, P(sb[0]), P(sb[1]), act, slope, cfg, st), "gemm_x3")
+            assert float((out.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()), (act, cfg)
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K + 1, N, B, 0, 0, 0, None, None, 0, 0.0, 0, st) == _lib.ARSEG_EINVAL
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, 0, 0.0, 6, st) == _lib.ARSEG_EINVAL
+
+
 @pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32), (3, 33, 70, 64, 128), (2, 7, 40, 64, 64)])
 def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     """PSPUpsample: F.upsample(x2, bilinear, align_corners=False) -> conv3x3 (+BN+PReLU), upsample fused into the Winograd
