@@ -27,13 +27,15 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 struct GX3Params {
     const unsigned char *X, *W;
     float *C;
-    const float *scale, *bias;
-    int M, N, K, ldc;
+    const float *scale, *bias, *res;
+    int M, N, K, ldc, res_ld, out_split;
     unsigned x_bytes, w_bytes;        // extent of one problem's operands (buffer descriptors)
     long long x_bs, w_bs, c_bs;       // batch strides: bytes, bytes, floats
     int tiles_m, tiles_n, batch;
     int act;
     float slope;
+    unsigned *range_flag;             // out_split: set when a value written as a split row exceeds range_limit (arseg_conv_desc.range_flag)
+    float range_limit;
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
@@ -194,6 +196,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     // epilogue: D[n][m]: lane (i16, kq) of fragment (a, c) holds channels n..n+3 (n = 16c + 4kq) of row m = 16a + i16
     float *__restrict__ C = p.C + (size_t)b * p.c_bs;
     const bool prelu = p.act == ARSEG_ACT_PRELU, relu = p.act == ARSEG_ACT_RELU, sigm = p.act == ARSEG_ACT_SIGMOID;
+    float vmax = 0.f;
 #pragma unroll
     for (int c = 0; c < WTN; ++c) {
         const int n = n0 + wn * (BN / NWN) + c * 16 + 4 * kq;
@@ -206,32 +209,47 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
             const int m = m0 + wm * (BM / NWM) + a * 16 + i16;
             if (m >= p.M) continue;
             f32x4 v = acc[a][c] * sc + bi;
+            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (relu) v[e] = fmaxf(v[e], 0.f);
                 else if (prelu) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
                 else if (sigm) v[e] = 1.0f / (1.0f + __expf(-v[e]));
             }
-            *reinterpret_cast<f32x4 *>(C + (size_t)m * p.ldc + n) = v;
+            if (p.out_split) {            // the output is the next GEMM's activation operand: written as split rows (ldc == N, N % 32 == 0)
+                unsigned h01, h23, l01, l23;
+                arseg_split_f16(v, h01, h23, l01, l23);
+                vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                unsigned char *o = reinterpret_cast<unsigned char *>(C) + ((size_t)m * p.N) * 4 + (n >> 5) * 128 + (n & 31) * 2;
+                *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+                *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
+            } else {
+                *reinterpret_cast<f32x4 *>(C + (size_t)m * p.ldc + n) = v;
+            }
         }
     }
+    if (p.range_flag && vmax > p.range_limit) atomicOr(p.range_flag, 1u);
 }
 
 // fp32 rows -> split rows (the operand layout above); 4 values per thread
-__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ in, long long in_ld, unsigned char *__restrict__ out, long long rows, int K, float mul) {
+__global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ in, long long in_ld, unsigned char *__restrict__ out, long long rows, int K, float mul,
+                                                         unsigned *range_flag, float range_limit) {
     const int k4 = K >> 2;
+    float vmax = 0.f;
     const long long total = rows * k4;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long r = idx / k4;
         const int c = (int)(idx - r * k4) * 4;
         f32x4 v = *reinterpret_cast<const f32x4 *>(in + r * in_ld + c);
         v *= mul;
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         unsigned h01, h23, l01, l23;
         arseg_split_f16(v, h01, h23, l01, l23);
         unsigned char *o = out + r * (long long)K * 4 + (c >> 5) * 128 + (c & 31) * 2;
         *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
         *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
     }
+    if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
 template <int NWM, int NWN, int WTM, int WTN, int ABL = 0>
@@ -261,30 +279,38 @@ int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
 
 }  // namespace
 
-extern "C" int arseg_split_rows_fwd(const float *in, long long in_ld, void *out, long long rows, int K, float mul, arseg_stream_t stream) {
+extern "C" int arseg_split_rows_fwd(const float *in, long long in_ld, void *out, long long rows, int K, float mul, void *range_flag,
+                                    float range_limit, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out);
+    if (reinterpret_cast<uintptr_t>(range_flag) & 3) return ARSEG_EINVAL;
     if (rows <= 0 || K <= 0 || (K & 31) || in_ld < K || (in_ld & 3) || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
     long long blocks = (rows * (K >> 2) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, arseg_stream(stream), in, in_ld, reinterpret_cast<unsigned char *>(out), rows, K, mul);
+    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, arseg_stream(stream), in, in_ld, reinterpret_cast<unsigned char *>(out), rows, K, mul,
+                       reinterpret_cast<unsigned *>(range_flag), range_limit > 0.0f ? range_limit : 65504.0f);
     return arseg_launch_status();
 }
 
 extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
                                  long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
-                                 const float *bias, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream) {
+                                 const float *bias, const float *residual, int res_ld, int act, float prelu_slope, int out_split, int tile_cfg,
+                                 void *range_flag, float range_limit, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(x_split); ARSEG_CHECK_PTR(w_split); ARSEG_CHECK_PTR(out);
     if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 3) || out_ld < N || (out_ld & 3) || batch <= 0) return ARSEG_EINVAL;
     if (!ARSEG_ALIGNED16(x_split) || !ARSEG_ALIGNED16(w_split) || !ARSEG_ALIGNED16(out) || (x_batch_stride & 15) || (w_batch_stride & 15) || (out_batch_stride & 3))
         return ARSEG_EINVAL;
     if ((scale && !ARSEG_ALIGNED16(scale)) || (bias && !ARSEG_ALIGNED16(bias))) return ARSEG_EINVAL;
+    if (residual && (batch > 1 || res_ld < N || (res_ld & 3) || !ARSEG_ALIGNED16(residual))) return ARSEG_EINVAL;
+    if (out_split && ((N & 31) || out_ld != N)) return ARSEG_EINVAL;
     if ((long long)M * K * 4 >= (1ll << 32) || (long long)N * K * 4 >= (1ll << 32)) return ARSEG_EUNSUPPORTED;      // 32-bit buffer offsets
     GX3Params p;
     p.X = reinterpret_cast<const unsigned char *>(x_split); p.W = reinterpret_cast<const unsigned char *>(w_split); p.C = out;
-    p.scale = scale; p.bias = bias; p.M = M; p.N = N; p.K = K; p.ldc = out_ld;
+    p.scale = scale; p.bias = bias; p.res = residual; p.res_ld = res_ld; p.out_split = out_split ? 1 : 0; p.M = M; p.N = N; p.K = K; p.ldc = out_ld;
     p.x_bytes = (unsigned)((long long)M * K * 4); p.w_bytes = (unsigned)((long long)N * K * 4);
     p.x_bs = batch > 1 ? x_batch_stride : 0; p.w_bs = batch > 1 ? w_batch_stride : 0; p.c_bs = batch > 1 ? out_batch_stride : 0;
     p.batch = batch; p.act = act; p.slope = prelu_slope;
+    if (reinterpret_cast<uintptr_t>(range_flag) & 3) return ARSEG_EINVAL;
+    p.range_flag = out_split ? reinterpret_cast<unsigned *>(range_flag) : nullptr; p.range_limit = range_limit > 0.0f ? range_limit : 65504.0f;
     hipStream_t hs = arseg_stream(stream);
     const int abl = tile_cfg >> 3;
     tile_cfg &= 7;

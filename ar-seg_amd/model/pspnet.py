@@ -57,7 +57,9 @@ class PSPModule(HipModule):
         pooled = ops.psp_pool_matrix(feats, self.sizes)
         t = ops.conv2d(pooled, pk["prior"])                                   # [N, rows, 1, 1024]: all levels, one launch
         prior = ops.psp_prior_sum(t.reshape(N, rows, -1), self.sizes, h, w)   # sum_s upsample(t_s), F.upsample default mode
-        return ops.conv2d(feats, pk["feat"], residual=prior)                  # + W_f f + b, ReLU
+        # + W_f f + b, ReLU.  The only consumer is up_1's low-resolution tap GEMM: with the LDS-DMA GEMM enabled the result is written as
+        # split rows (ops.SplitRows) and up_1 stages it without a conversion; otherwise this is an ordinary fp32 NHWC tensor
+        return ops.conv2d(feats, pk["feat"], residual=prior, out_split=True)
 
 
 class PSPUpsample(HipModule):

@@ -37,7 +37,8 @@ class Config:
     conv_find        [ARSEG_CONV_FIND = native | python]        who times the candidate plans: arseg_conv2d_find or the host loop
     conv_winograd    [ARSEG_CONV_WINOGRAD = 1 | 0]              let the tuner consider Winograd F(4x4,3x3)
     conv_up2_taps    [ARSEG_CONV_UP2_TAPS = 1 | 0]              let the tuner consider the tap decomposition for convs after a x2 upsample
-    conv_gemm_x3     [ARSEG_CONV_GEMM_X3 = 1 | 0]               let the tuner consider the LDS-DMA GEMM on pre-split operands (csrc/gemm_x3.hip)
+    conv_gemm_x3     [ARSEG_CONV_GEMM_X3 = 1 | wino | 0]        let the tuner consider the LDS-DMA GEMM on pre-split operands (csrc/gemm_x3.hip): for
+                     the Winograd GEMMs, the 1x1 convs and the PSP bottleneck -> up_1 chain on split rows (1), the Winograd GEMMs only (wino)
     conv_range_guard [ARSEG_CONV_RANGE_GUARD = device | host | 0]   operand range of the f16x3 back end: sticky device word read by
                      ops.range_tripped() (default) / amax + host sync per conv with an immediate fp32 fallback / off
     conv_plan_file   [ARSEG_CONV_PLAN_FILE = <json>]            persist the tuned plans
@@ -50,7 +51,7 @@ class Config:
     conv_find: str = "native"
     conv_winograd: bool = True
     conv_up2_taps: bool = True
-    conv_gemm_x3: bool = True
+    conv_gemm_x3: object = True          # True | "wino" | False
     conv_range_guard: str = "device"
     conv_plan_file: Optional[str] = None
     creff_impl: str = ""
@@ -62,7 +63,7 @@ class Config:
         e = os.environ.get
         return cls(conv_math=e("ARSEG_CONV_MATH", "f16x3"), conv_autotune=e("ARSEG_CONV_AUTOTUNE", "1") != "0",
                    conv_find=e("ARSEG_CONV_FIND", "native"), conv_winograd=e("ARSEG_CONV_WINOGRAD", "1") != "0",
-                   conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0", conv_gemm_x3=e("ARSEG_CONV_GEMM_X3", "1") != "0",
+                   conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0", conv_gemm_x3={"0": False, "wino": "wino"}.get(e("ARSEG_CONV_GEMM_X3", "1"), True),
                    conv_range_guard={"1": "host", "host": "host", "0": "off", "off": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), "device"),
                    conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=int(e("ARSEG_CREFF_TY", "0") or 0),
                    lr_subbatch=int(e("ARSEG_LR_SUBBATCH", "0") or 0))
@@ -629,16 +630,122 @@ def _conv_candidates(ktiles: int, cout: int, m: int, patch_ok: bool = False):
     return cands
 
 
+class SplitRows:
+    """An NHWC activation tensor stored as split rows -- per 32 channels 32 hi fp16 halves then 32 lo halves, the operand format of
+    arseg_gemm_x3_fwd (include/arseg_hip.h) -- in a float32-typed buffer ``t`` of the logical shape (the same 4 bytes per value).
+    Produced by ``conv2d(..., out_split=True)`` / ``split_rows``; consumed by ``conv2d`` (1x1 convs and the tap-decomposed conv after a
+    x2 upsample).  ``float()`` gives the fp32 tensor back (torch ops on the device; only fallback paths need it)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    shape = property(lambda self: self.t.shape)
+    device = property(lambda self: self.t.device)
+
+    def float(self):
+        n, h, w, c = self.t.shape
+        hl = self.t.view(torch.float16).view(n, h, w, c // 32, 2, 32).float()
+        return (hl[..., 0, :] + hl[..., 1, :]).reshape(n, h, w, c)
+
+
+def gemm_x3_enabled() -> bool:
+    return _GEMM_X3 is True and _math == _lib.MATH_F16X3 and not _RANGE_GUARD
+
+
+def split_rows(x: torch.Tensor) -> SplitRows:
+    """fp32 NHWC [N,H,W,C] (C % 32 == 0; may be a channel slice) -> SplitRows: one memory-bound pass (arseg_split_rows_fwd) that also
+    carries the operand range watch of the GEMM that will consume it."""
+    _need_gpu(x)
+    n, h, w, c = x.shape
+    t = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    rw = _range_word(x.device) if _RANGE_MODE == "device" else None
+    _launch("split_rows", _lib.load().arseg_split_rows_fwd, _ptr(x), _nhwc_ld(x), _ptr(t), n * h * w, c, 1.0, _ptr(rw), 65504.0, _stream())
+    return SplitRows(t)
+
+
+def _x3_eligible(pc, cin, residual, up2) -> bool:
+    return (gemm_x3_enabled() and not up2 and pc.R == 1 and pc.S == 1 and pc.stride == 1 and pc.pad == 0 and cin % 32 == 0 and cin == pc.cin_pad
+            and pc.cout % 4 == 0)
+
+
+def _conv1x1_x3(x, pc, residual=None, out=None, out_split=False, cfg=None, record=True):
+    """1x1 stride-1 conv on the LDS-DMA GEMM (csrc/gemm_x3.hip).  x: SplitRows, or fp32 NHWC (split by a pre-pass first).  cfg None: the
+    tile shape is timed on first use per (M, K, N)."""
+    lib = _lib.load()
+    xs = x if isinstance(x, SplitRows) else split_rows(x)
+    N, H, W, Cin = xs.shape
+    M, Cout, dev = N * H * W, pc.cout, xs.device
+    if out_split:
+        if Cout % 32:
+            raise _lib.ArsegError("out_split needs Cout % 32 == 0")
+        out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    elif out is None:
+        out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    rw = _range_word(dev) if (out_split and _RANGE_MODE == "device") else None
+
+    def run(c, rec):
+        args = (_ptr(xs.t), _ptr(pc.w_h3), _ptr(out), M, Cout, Cin, Cout if out_split else _nhwc_ld(out), 1, 0, 0, 0, _ptr(pc.scale_h3), _ptr(pc.bias),
+                _ptr(residual), _nhwc_ld(residual) if residual is not None else 0, pc.act, pc.slope, 1 if out_split else 0, c, _ptr(rw), 65504.0, _stream())
+        if rec:
+            _launch("conv2d", lib.arseg_gemm_x3_fwd, *args, flops=2 * M * Cin * Cout)
+        else:
+            check(lib.arseg_gemm_x3_fwd(*args), "gemm_x3")
+
+    if cfg is None:
+        key = ("x3", dev.index, M, Cin, Cout, bool(out_split), residual is not None)
+        cfg = _conv_plans.get(key)
+        if cfg is None:
+            best_t = float("inf")
+            for c in range(6):
+                t = _time(lambda: run(c, False))
+                if t < best_t:
+                    cfg, best_t = c, t
+            _conv_plans[key] = cfg
+    run(cfg, record)
+    return SplitRows(out) if out_split else out
+
+
 def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
-           tile_cfg: int = 0, split_k: int = 0, up2: bool = False) -> torch.Tensor:
+           tile_cfg: int = 0, split_k: int = 0, up2: bool = False, out_split: bool = False):
     """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view.
     tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use).
     up2: the conv input is the x2 bilinear (align_corners=False) upsample of ``x`` (PSPUpsample, model/pspnet.py:43-46);
     the Winograd route applies it inside its input transform, the patch-resident direct plans while they stage their input patch;
     the GEMM-tile plans materialise it first."""
+    global _layer_tag
+    if isinstance(x, SplitRows):
+        # an activation the producer already wrote as split rows: 1x1 convs go straight to the LDS-DMA GEMM, a 3x3 conv after a x2 upsample
+        # to its tap decomposition (whose low-resolution 1x1 conv is such a GEMM); anything else reads the fp32 form
+        n_, h_, w_, c_ = x.shape
+        if not up2 and _x3_eligible(pc, c_, residual, False):
+            return _conv1x1_x3(x, pc, residual, out, out_split)
+        if (up2 and gemm_x3_enabled() and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.dil == 1
+                and pc.cout % 4 == 0 and c_ % 32 == 0):
+            if out is None:
+                out = torch.empty((n_, 2 * h_, 2 * w_, pc.cout), dtype=torch.float32, device=x.device)
+            outer_tag = _layer_tag
+            if _profile is not None and outer_tag is None:
+                _layer_tag = (n_, 2 * h_, 2 * w_, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, True, "taps(x3)", 2 * n_ * 4 * h_ * w_ * pc.cout * 9 * pc.cin)
+            try:
+                _conv_up2_taps(x, pc, out)
+            finally:
+                _layer_tag = outer_tag
+            return out
+        return conv2d(x.float(), pc, residual, out, tile_cfg, split_k, up2, out_split)
     if is16(x):
         return _conv2d16(x, pc, residual, out, up2, tile_cfg, split_k)
     _need_gpu(x, residual, out)
+    if out_split and tile_cfg == 0 and split_k == 0 and out is None and _x3_eligible(pc, x.shape[3], residual, up2) and pc.cout % 32 == 0:
+        # the consumer takes split rows (e.g. the PSP bottleneck feeding up_1): this conv runs on the LDS-DMA GEMM and writes them
+        outer_tag = _layer_tag
+        if _profile is not None and outer_tag is None:
+            n_, h_, w_, c_ = x.shape
+            _layer_tag = (n_, h_, w_, pc.cin, pc.cout, 1, 1, 1, False, "x3(split out)", 2 * n_ * h_ * w_ * pc.cout * pc.cin)
+        try:
+            return _conv1x1_x3(x, pc, residual, None, True)
+        finally:
+            _layer_tag = outer_tag
     if _RANGE_GUARD and _math == _lib.MATH_F16X3 and not (float(x.abs().max()) <= _RANGE_LIMIT):      # (NaN compares false)
         prev = set_conv_math("f32")
         try:
@@ -712,6 +819,9 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     def launch_taps(record=True):
         _conv_up2_taps(x_low, pc, out, record)
 
+    def launch_x3(record=True):
+        _conv1x1_x3(x, pc, residual, out, False, None, record)
+
     def find_native():
         """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
         fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
@@ -734,8 +844,9 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         wino_ok = getattr(pc, "wino_u", None) is not None and _WINOGRAD
         taps_ok = (x_low is not None and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
                    and pc.dil == 1 and pc.cout % 4 == 0)
+        x3_ok = _x3_eligible(pc, Cin, residual, x_low is not None) and not wino_ok
         plan = _conv_plans.get(key)
-        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or plan == "tapsf":      # a persisted plan whose route is switched off / gone: re-tune
+        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or plan == "tapsf":      # a persisted plan whose route is switched off / gone: re-tune
             plan = None
         if plan is None:
             plan = find_native() if _NATIVE_FIND else None
@@ -764,6 +875,14 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "wino"
                 except _lib.ArsegError:
                     pass                                        # the Winograd route does not cover this shape: keep the direct plan
+            if x3_ok:                                           # split pre-pass + LDS-DMA GEMM against the best implicit-GEMM plan
+                try:
+                    t_direct = _time(lambda: launch(*plan, record=False))
+                    launch_x3(record=False)                     # picks its tile shape
+                    if _time(lambda: launch_x3(record=False)) < t_direct:
+                        plan = "x3"
+                except _lib.ArsegError:
+                    pass
             if taps_ok:
                 try:
                     t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: launch(*plan, record=False)))
@@ -773,7 +892,6 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 except _lib.ArsegError:
                     pass
             _conv_plans[key] = plan
-        global _layer_tag
         outer_tag = _layer_tag          # the tap-decomposed route calls conv2d for its low-resolution GEMM: the outermost layer keeps the tag
         if _profile is not None and outer_tag is None:
             _layer_tag = (N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, x_low is not None, str(plan), flops)
@@ -782,6 +900,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 launch_wino()
             elif plan == "taps":
                 launch_taps()
+            elif plan == "x3":
+                launch_x3()
             else:
                 launch(*plan)
         finally:
@@ -898,7 +1018,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     d.math = math = _math
     _arm_range_watch(d, x.device)          # the batched GEMM watches the transformed activations it multiplies
     u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math != _lib.MATH_F32 else (pc.wino_u, pc.scale)
-    x3_ok = _GEMM_X3 and math == _lib.MATH_F16X3 and Cin % 32 == 0 and Cout % 4 == 0
+    x3_ok = bool(_GEMM_X3) and math == _lib.MATH_F16X3 and Cin % 32 == 0 and Cout % 4 == 0
     key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
     plan = _conv_plans.get(key)
     if plan is not None and plan >= 100 and not x3_ok:
@@ -914,7 +1034,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
     def gemm(cfg, rec):
         if cfg >= 100:
             fn, args = lib.arseg_gemm_x3_fwd, (_ptr(V), _ptr(u_dev), _ptr(M), T, Cout, Cin, Cout, 36, T * Cin * 4, Cout * Cin * 4, T * Cout,
-                                               _ptr(None), _ptr(None), _lib.ACT_NONE, 0.0, cfg - 100, _stream())
+                                               _ptr(None), _ptr(None), _ptr(None), 0, _lib.ACT_NONE, 0.0, 0, cfg - 100, _ptr(None), 0.0, _stream())
         else:
             d.tile_cfg, d.split_k = cfg, 1
             fn, args = lib.arseg_conv2d_fwd, (ctypes.byref(d), _ptr(V), _ptr(u_dev), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())

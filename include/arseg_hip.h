@@ -243,15 +243,22 @@ int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bia
 
 /* Batched GEMM on operands that are already split into fp16 (hi, lo) pairs ("split rows": a row of K values, K % 32 == 0, is K/32
  * groups of 128 bytes = 32 hi halves then 32 lo halves; the f16x3 weight format of arseg_split_weight_f16x3_host, now also for the
- * activations):   out[b][m][n] = act(scale[n] * sum_k x[b][m][k] * w[b][n][k] + bias[n])       (scale / bias may be NULL)
+ * activations):   out[b][m][n] = act(scale[n] * sum_k x[b][m][k] * w[b][n][k] + bias[n] + residual[m][n])   (scale / bias / residual may
+ * be NULL; residual fp32 [M][res_ld], batch == 1 only)
  * x_split [batch][M][K], w_split [batch][N][K] in split rows (batch strides in BYTES, multiples of 16), out fp32 [batch][M][out_ld]
- * (stride in floats), N % 4 == 0.  Operands reach LDS by LDS-DMA, no register staging (csrc/gemm_x3.hip).  tile_cfg 0..3 = 256x256,
- * 128x256, 256x128, 128x128 (M x N per workgroup).  The same fp32-grade arithmetic as ARSEG_MATH_F16X3 (three fp16 MFMAs per product).
- * arseg_split_rows_fwd converts fp32 rows [rows][in_ld] (times `mul`, a power of two keeps it exact) to split rows [rows][K]. */
-int arseg_split_rows_fwd(const float *in, long long in_ld, void *out_split, long long rows, int K, float mul, arseg_stream_t stream);
+ * (stride in floats), N % 4 == 0.  Operands reach LDS by LDS-DMA, no register staging (csrc/gemm_x3.hip).  tile_cfg 0..5
+ * (M x N per workgroup): 0 = 256x256 with 8 waves, 1 = 256x256 with 16, 2 / 5 = 128x256 with 8 / 16, 3 = 128x128,
+ * 4 = 256x128.  out_split != 0: `out` is written as split rows too (N % 32 == 0, out_ld == N) -- it is the next GEMM's x_split, e.g. the
+ * PSP bottleneck feeding the tap-decomposed up_1 conv.  The same fp32-grade arithmetic as ARSEG_MATH_F16X3 (three fp16 MFMAs per product).
+ * arseg_split_rows_fwd converts fp32 rows [rows][in_ld] (times `mul`, a power of two keeps it exact) to split rows [rows][K].
+ * range_flag / range_limit (may be NULL / <= 0: 65504): the operand range word of arseg_conv_desc, set by whoever WRITES split rows from
+ * fp32 values (the split pass, a GEMM with out_split) -- the consuming GEMM never sees the fp32 operand. */
+int arseg_split_rows_fwd(const float *in, long long in_ld, void *out_split, long long rows, int K, float mul, void *range_flag,
+                         float range_limit, arseg_stream_t stream);
 int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
                       long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
-                      const float *bias, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream);
+                      const float *bias, const float *residual, int res_ld, int act, float prelu_slope, int out_split, int tile_cfg,
+                      void *range_flag, float range_limit, arseg_stream_t stream);
 
 /* conv3x3 (pad 1, stride 1) of a x2 bilinear (align_corners=False) upsample -- PSPUpsample, /root/reference/model/pspnet.py:43-46 --
  * by tap decomposition: since a 1x1 conv commutes with a per-channel resize, conv3x3(Up(x)) = sum_t shift_t(Up(W_t x)).  The caller

@@ -535,6 +535,55 @@ def test_conv2d_winograd_gemm_x3(dev, N, H, W, Cin, Cout, dil, up2):
             ops._conv_plans[key] = saved
 
 
+@pytest.mark.parametrize("N,h,w,Cin,Cmid,Cout", [(2, 9, 13, 64, 128, 64), (1, 16, 32, 512, 1024, 256), (1, 5, 7, 96, 32, 12)])
+def test_conv_chain_split_rows(dev, N, h, w, Cin, Cmid, Cout):
+    """The PSP bottleneck -> up_1 chain on split rows: a 1x1 conv (+ residual, ReLU) on the LDS-DMA GEMM writing ops.SplitRows, consumed by the
+    tap-decomposed conv3x3-after-upsample (its low-resolution GEMM stages the split rows directly) -- against F.conv2d / F.interpolate; plus
+    the same 1x1 conv with fp32 output (split pre-pass route), SplitRows.float(), and a consumer that has to fall back to the fp32 form."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    prev = ops.set_conv_math("f16x3")
+    try:
+        assert ops.gemm_x3_enabled()
+        x = rnd(400, N, Cin, h, w)
+        w1 = rnd(401, Cmid, Cin, 1, 1, scale=float(np.sqrt(2.0 / Cin)))
+        b1 = rnd(402, Cmid, scale=0.1)
+        res = rnd(403, N, Cmid, h, w)
+        w3 = rnd(404, Cout, Cmid, 3, 3, scale=float(np.sqrt(2.0 / (9 * Cmid))))
+        b3 = rnd(405, Cout, scale=0.1)
+        pc1 = PackedConv(w1, b1, None, 1, 0, 1, _lib.ACT_RELU, 0.0, dev)
+        pc3 = PackedConv(w3, b3, None, 1, 1, 1, _lib.ACT_PRELU, 0.25, dev)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(dev)
+        mid_want = F.relu(F.conv2d(x.double(), w1.double(), b1.double()) + res.double())
+        mid = ops.conv2d(xd, pc1, residual=rd, out_split=True)
+        assert isinstance(mid, ops.SplitRows)
+        assert maxdiff(mid.float().permute(0, 3, 1, 2), mid_want.float()) <= 2e-5
+        plain = ops._conv1x1_x3(xd, pc1, rd)                       # fp32 output
+        assert maxdiff(plain.permute(0, 3, 1, 2), mid_want.float()) <= 2e-5
+        assert maxdiff(plain, mid.float()) <= 1e-6 * float(mid_want.abs().max())      # the split rows carry 22 bits of the same values
+        up = F.interpolate(mid_want, scale_factor=2.0, mode="bilinear", align_corners=False)
+        want = F.prelu(F.conv2d(up, w3.double(), b3.double(), padding=1), torch.tensor([0.25], dtype=torch.float64)).float()
+        got = ops.conv2d(mid, pc3, up2=True)
+        assert maxdiff(got.permute(0, 3, 1, 2), want) <= 5e-5
+        got_fp32_in = ops.conv2d(plain, pc3, up2=True)             # whatever plan the tuner picks for the fp32 input
+        assert maxdiff(got_fp32_in, got) <= 1e-4
+        # a consumer without a split-row route (3x3 at the same resolution) reads the fp32 form
+        same = ops.conv2d(mid, pc3)
+        want_same = F.prelu(F.conv2d(mid_want, w3.double(), b3.double(), padding=1), torch.tensor([0.25], dtype=torch.float64)).float()
+        assert maxdiff(same.permute(0, 3, 1, 2), want_same) <= 2e-4
+        # with the route switched off the same call returns an ordinary tensor
+        old = ops.configure(conv_gemm_x3=False)
+        try:
+            t_plain = ops.conv2d(xd, pc1, residual=rd, out_split=True)
+            assert isinstance(t_plain, torch.Tensor) and maxdiff(t_plain.permute(0, 3, 1, 2), mid_want.float()) <= 2e-5
+        finally:
+            ops.configure(**old)
+    finally:
+        ops.set_conv_math(prev)
+
+
 @pytest.mark.parametrize("B,M,K,N", [(1, 1, 32, 4), (3, 300, 96, 36), (2, 257, 64, 260), (1, 1000, 256, 512), (36, 130, 128, 64)])
 def test_gemm_x3(dev, B, M, K, N):
     """arseg_split_rows_fwd + arseg_gemm_x3_fwd (every tile_cfg; ragged M and N tails, single-step K, scale / bias / activation epilogue)
@@ -551,8 +600,8 @@ def test_gemm_x3(dev, B, M, K, N):
     w = rnd(301, B, N, K, scale=0.1).to(dev)
     scale, bias = torch.from_numpy(g.uniform(0.5, 1.5, N).astype(np.float32)).to(dev), rnd(302, N).to(dev)
     xs, ws = torch.empty_like(x), torch.empty_like(w)
-    _lib.check(lib.arseg_split_rows_fwd(P(x), K, P(xs), B * M, K, 1.0, st), "split")
-    _lib.check(lib.arseg_split_rows_fwd(P(w), K, P(ws), B * N, K, 1.0, st), "split")
+    _lib.check(lib.arseg_split_rows_fwd(P(x), K, P(xs), B * M, K, 1.0, None, 0.0, st), "split")
+    _lib.check(lib.arseg_split_rows_fwd(P(w), K, P(ws), B * N, K, 1.0, None, 0.0, st), "split")
     # the split rows hold hi + lo = x to 22 bits
     raw = xs.view(torch.float16).view(B, M, K // 32, 2, 32).float()
     assert float((raw[:, :, :, 0] + raw[:, :, :, 1] - x.view(B, M, K // 32, 32)).abs().max()) <= 2.0 ** -21 * float(x.abs().max())
@@ -562,10 +611,10 @@ def test_gemm_x3(dev, B, M, K, N):
         for cfg in range(6):
             out = torch.full((B, M, N), float("nan"), device=dev)
             sb = (None, None) if act == _lib.ACT_NONE else (scale, bias)
-            _lib.check(lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, P(sb[0]), P(sb[1]), act, slope, cfg, st), "gemm_x3")
+            _lib.check(lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, P(sb[0]), P(sb[1]), None, 0, act, slope, 0, cfg, None, 0.0, st), "gemm_x3")
             assert float((out.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()), (act, cfg)
-    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K + 1, N, B, 0, 0, 0, None, None, 0, 0.0, 0, st) == _lib.ARSEG_EINVAL
-    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, 0, 0.0, 6, st) == _lib.ARSEG_EINVAL
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K + 1, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 0, None, 0.0, st) == _lib.ARSEG_EINVAL
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 6, None, 0.0, st) == _lib.ARSEG_EINVAL
 
 
 @pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32), (3, 33, 70, 64, 128), (2, 7, 40, 64, 64)])

@@ -69,8 +69,8 @@ def main():
         w = (torch.randn(B, N, K, generator=g) * 0.05).to(dev)
         xs = torch.empty(B, M, K, dtype=torch.float32, device=dev)      # split rows occupy the same 4 bytes per value
         ws = torch.empty(B, N, K, dtype=torch.float32, device=dev)
-        _lib.check(lib.arseg_split_rows_fwd(ptr(x), K, ptr(xs), B * M, K, 1.0, st), "split x")
-        _lib.check(lib.arseg_split_rows_fwd(ptr(w), K, ptr(ws), B * N, K, 1.0, st), "split w")
+        _lib.check(lib.arseg_split_rows_fwd(ptr(x), K, ptr(xs), B * M, K, 1.0, None, 0.0, st), "split x")
+        _lib.check(lib.arseg_split_rows_fwd(ptr(w), K, ptr(ws), B * N, K, 1.0, None, 0.0, st), "split w")
         out = torch.empty(B, M, N, dtype=torch.float32, device=dev)
         ref = torch.bmm(x.double(), w.double().transpose(1, 2))
         rmax = ref.abs().max().item()
@@ -81,7 +81,7 @@ def main():
             out.zero_()
 
             def run(cfg=cfg):
-                _lib.check(lib.arseg_gemm_x3_fwd(ptr(xs), ptr(ws), ptr(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, None, None, 0, 0.0, cfg, st), "gemm_x3")
+                _lib.check(lib.arseg_gemm_x3_fwd(ptr(xs), ptr(ws), ptr(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, None, None, None, 0, 0, 0.0, 0, cfg, None, 0.0, st), "gemm_x3")
 
             run()
             torch.cuda.synchronize()
