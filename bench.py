@@ -397,14 +397,14 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         ky = prof_key.summary()
         conv = nk["conv2d"]
         conv_k = ky["conv2d"]
-        # ---- conv family (conv_igemm_kernel<...> + conv3x3_patch_kernel<...>): MFMA-bound.  `frac` = the reference's direct-conv FLOP count
+        # ---- conv family (conv_igemm_kernel<...> + gemm_x3_kernel<...> + conv3x3_patch_kernel<...>): MFMA-bound.  `frac` = the reference's direct-conv FLOP count
         # (2 x MACs of every conv / linear, hook-counted on the reference: 11 x 116.9 + 468.2 GFLOP per GOP at the headline
         # config) / the kernels' summed time / the dense fp16 MFMA peak.  `mfma_issue_frac` = what the matrix cores actually execute
         # (GEMM FLOPs x 3 under f16x3: hi.hi + hi.lo + lo.hi) against the same peak -- issue rate, not work.
         tot_flops = conv["flops"] / 3 + conv_k["flops"]
         tot_ms = conv["ms"] / 3 + conv_k["ms"]
         n_launch = conv["launches"] / 3 + conv_k["launches"]
-        aux = ("wino_input", "wino_output", "up2_tap_gather")      # memory-bound passes that belong to a conv: Winograd transforms, tap gather
+        aux = ("wino_input", "wino_output", "up2_tap_gather", "split_rows")      # memory-bound passes that belong to a conv: Winograd transforms, tap gather, split pre-pass
         wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in aux) / 3 + sum(ky.get(k, {"ms": 0.0})["ms"] for k in aux)
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9
         mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]
@@ -422,7 +422,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         ref_tf = ref_flops / (tot_ms * 1e-3) / 1e12 if ref_flops else None
         result["roofline_conv"] = {
             "kernel": ("conv16_kernel<BF,CO_T> (implicit GEMM on 16-bit NHWC tensors, one v_mfma_f32_32x32x16_" + ("bf16" if storage == "bf16" else "f16") + " per product)") if storage != "f32" else
-                      "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / batched Winograd GEMM; " +
+                      "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + gemm_x3_kernel<NWM,NWN,WTM,WTN> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / LDS-DMA GEMM on pre-split operands for the batched Winograd and 1x1 GEMMs / patch-resident 3x3; " +
                       {"f16x3": "3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)", "f16": "v_mfma_f32_32x32x16_f16 on fp16-rounded operands)",
                        "f32": "v_mfma_f32_32x32x2_f32)"}[args.conv_math],
             "bound": "mfma", "achieved": ref_tf, "peak": peak, "unit": "TFLOP/s",

@@ -241,7 +241,9 @@ int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bia
                             int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale,
                             arseg_stream_t stream);
 
-/* Batched GEMM on operands that are already split into fp16 (hi, lo) pairs ("split rows": a row of K values, K % 32 == 0, is K/32
+/* (Part of the nn.Conv2d replacement above: the GEMM inside conv3x3 on the Winograd route, /root/reference/model/extractors.py:30-32,
+ * the 1x1 bottleneck of PSPModule, model/pspnet.py:26, and the low-resolution tap GEMM of PSPUpsample, model/pspnet.py:38-46.)
+ * Batched GEMM on operands that are already split into fp16 (hi, lo) pairs ("split rows": a row of K values, K % 32 == 0, is K/32
  * groups of 128 bytes = 32 hi halves then 32 lo halves; the f16x3 weight format of arseg_split_weight_f16x3_host, now also for the
  * activations):   out[b][m][n] = act(scale[n] * sum_k x[b][m][k] * w[b][n][k] + bias[n] + residual[m][n])   (scale / bias / residual may
  * be NULL; residual fp32 [M][res_ld], batch == 1 only)

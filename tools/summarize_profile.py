@@ -41,7 +41,7 @@ if fs:
         if v.get("GRBM_GUI_ACTIVE"):
             e["mfma_util"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (128.0 * v["GRBM_GUI_ACTIVE"])
     res["note"] += "; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES (summed over all SIMDs) / (128 SIMDs per XCD x GRBM_GUI_ACTIVE, which is reported summed over the 8 XCDs: checked on creff_rr_kernel, 43.25 M MFMAs x 16 cycles over a 2.9 ms launch), separate --pmc pass, dispatches serialised by the profiler"
-conv = [v for k, v in res["kernels"].items() if k.startswith("conv_igemm_kernel") or k.startswith("conv3x3_patch_kernel") or k.startswith("conv16")]
+conv = [v for k, v in res["kernels"].items() if k.startswith("conv_igemm_kernel") or k.startswith("gemm_x3_kernel") or k.startswith("conv3x3_patch_kernel") or k.startswith("conv16")]
 if conv:
     n = sum(v["launches"] for v in conv)
     fetch = sum(v.get("fetch_kib_avg", 0) * v["launches"] for v in conv) / n; write = sum(v.get("write_kib_avg", 0) * v["launches"] for v in conv) / n
