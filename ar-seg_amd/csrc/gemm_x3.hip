@@ -14,8 +14,9 @@
 //   * the LDS image is the linear image the DMA writes (8 rows x 128 B per instruction); bank conflicts of the fragment reads are
 //     removed by permuting the SOURCE 16-byte slots of a row (slot ^ ((row >> 1) & 7)) and applying the same XOR on the read: the
 //     four 16-lane groups of a ds_read_b128 then touch 16 distinct slots of the 256-byte bank row;
-//   * a 256 x 256 tile per workgroup of 8 waves (2 x 4; 128 x 64 per wave = 32 accumulator fragments), one 128-byte group per
-//     K step, double buffered (128 KiB): 96 MFMAs per wave and K step against 24 ds_read_b128, ONE barrier per K step;
+//   * tiles of 128 x 128 ... 256 x 256 per workgroup of 8 or 16 waves (tile_cfg, timed per shape), one 128-byte group per K step, double
+//     buffered, ONE barrier per K step; tile_cfg 6 runs the 16 waves of a 256 x 256 tile as two groups half a K step apart (see STAG below):
+//     while one group issues MFMAs the other reads fragments and requests the next step (-12 % on the largest GEMM);
 //   * D is computed transposed (weights as the MFMA's A operand) so that a lane holds 4 consecutive output channels: 16-byte stores.
 #include "arseg_common.h"
 
@@ -52,7 +53,7 @@ __device__ __forceinline__ void dma16_buf(const u32x4 rsrc, unsigned voff, unsig
 }
 
 // NWM x NWN waves; 16-row fragments per wave: WTM along M (activation rows), WTN along N (weight rows)
-template <int NWM, int NWN, int WTM, int WTN, int ABL = 0>
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params p) {
     constexpr int NW = NWM * NWN, BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
     constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
@@ -184,6 +185,60 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
             pxl[a] = *reinterpret_cast<const h16x8 *>(smem + (xo ^ 64u) + a * 2048);
         }
     }
+    if constexpr (STAG) {
+        // Two wave groups half a K step apart (each SIMD hosts two waves of either group): a K step is read(half 0) | MFMA(half 0) | read(half 1) |
+        // MFMA(half 1), separated by barriers, and group 1 starts one barrier late -- while one group issues MFMAs the other reads fragments and
+        // requests the next K step, instead of all 16 waves doing the same thing at the same time.  Hand-over rules: fragment reads are retired
+        // (lgkmcnt) before the barrier that ends their segment, so a stage may be refilled by whoever passes that barrier; the requests of step
+        // kt + 1 go out in read(half 0) of step kt and are retired (vmcnt) by each wave before the last barrier the EARLIER group passes in step kt.
+        static_assert(WTM / HM == 2, "two halves");
+        const int grp = (wave >> 2) & 1;
+        auto bar = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        if (grp) bar();
+#pragma unroll 1
+        for (int kt = 0; kt < nk; ++kt) {
+            const unsigned char *base = smem + (kt & 1) * STAGE;
+            h16x8 wh[WTN], wl[WTN], xh[HM], xl[HM];
+#pragma unroll
+            for (int c = 0; c < WTN; ++c) {
+                wh[c] = *reinterpret_cast<const h16x8 *>(base + wo + c * 2048);
+                wl[c] = *reinterpret_cast<const h16x8 *>(base + (wo ^ 64u) + c * 2048);
+            }
+#pragma unroll
+            for (int a = 0; a < HM; ++a) {
+                xh[a] = *reinterpret_cast<const h16x8 *>(base + xo + a * 2048);
+                xl[a] = *reinterpret_cast<const h16x8 *>(base + (xo ^ 64u) + a * 2048);
+            }
+            if (kt + 1 < nk) {
+                issue_x(kt + 1, (kt & 1) ^ 1);
+                issue_w(kt + 1, (kt & 1) ^ 1);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(0, wh, wl, xh, xl);
+            __builtin_amdgcn_s_setprio(0);
+            bar();
+#pragma unroll
+            for (int a = 0; a < HM; ++a) {
+                xh[a] = *reinterpret_cast<const h16x8 *>(base + xo + (HM + a) * 2048);
+                xl[a] = *reinterpret_cast<const h16x8 *>(base + (xo ^ 64u) + (HM + a) * 2048);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+            __builtin_amdgcn_s_setprio(1);
+            mfmas(1, wh, wl, xh, xl);
+            __builtin_amdgcn_s_setprio(0);
+            if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            bar();
+        }
+        if (!grp) bar();
+    } else {
 #pragma unroll 1
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -191,6 +246,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
         compute(NOREAD ? 0 : cur, (kt + 1 < nk && !NODMA) ? kt + 1 : -1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+    }
     }
 
     // epilogue: D[n][m]: lane (i16, kq) of fragment (a, c) holds channels n..n+3 (n = 16c + 4kq) of row m = 16a + i16
@@ -252,15 +308,15 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
-template <int NWM, int NWN, int WTM, int WTN, int ABL = 0>
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
 int launch_x3(GX3Params &p, hipStream_t hs) {
     constexpr int BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
     p.tiles_m = arseg_cdiv(p.M, BM); p.tiles_n = arseg_cdiv(p.N, BN);
     if ((long long)p.tiles_m * p.tiles_n * p.batch >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const size_t smem = (size_t)2 * (BM + BN) * 128;
     static ArsegSmemAttr attr;
-    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL>), smem)) return e;
-    hipLaunchKernelGGL((gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL>), dim3(p.tiles_m * p.tiles_n * p.batch), dim3(64 * NWM * NWN), smem, hs, p);
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG>), smem)) return e;
+    hipLaunchKernelGGL((gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG>), dim3(p.tiles_m * p.tiles_n * p.batch), dim3(64 * NWM * NWN), smem, hs, p);
     return arseg_launch_status();
 }
 
@@ -273,6 +329,7 @@ int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
         case 3: return launch_x3<2, 4, 4, 2, ABL>(p, hs);      // 128 x 128,  8 waves
         case 4: return launch_x3<4, 4, 4, 2, ABL>(p, hs);      // 256 x 128, 16 waves
         case 5: return launch_x3<4, 4, 2, 4, ABL>(p, hs);      // 128 x 256, 16 waves
+        case 6: return launch_x3<4, 4, 4, 4, ABL, true>(p, hs);   // 256 x 256, 16 waves in two staggered groups
         default: return ARSEG_EINVAL;
     }
 }

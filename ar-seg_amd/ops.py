@@ -697,7 +697,7 @@ def _conv1x1_x3(x, pc, residual=None, out=None, out_split=False, cfg=None, recor
         cfg = _conv_plans.get(key)
         if cfg is None:
             best_t = float("inf")
-            for c in range(6):
+            for c in range(7):
                 t = _time(lambda: run(c, False))
                 if t < best_t:
                     cfg, best_t = c, t
@@ -1057,7 +1057,7 @@ def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
                 best, best_t = cfg, t
         if x3_ok:
             transform(True, quiet)
-            for cfg in range(100, 106):
+            for cfg in range(100, 107):
                 t = _time(lambda: gemm(cfg, False))
                 if t < best_t:
                     best, best_t = cfg, t

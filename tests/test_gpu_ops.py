@@ -519,13 +519,13 @@ def test_conv2d_winograd_gemm_x3(dev, N, H, W, Cin, Cout, dil, up2):
     saved = ops._conv_plans.get(key)
     try:
         outs = {}
-        for plan in (7, 100, 101, 102, 103, 104, 105):
+        for plan in (7, 100, 101, 102, 103, 104, 105, 106):
             ops._conv_plans[key] = plan
             out = torch.full((N, H, W, Cout), float("nan"), device=dev)
             ops._conv_wino(xd, pc, None, out, N, H, W, up2=up2)
             outs[plan] = out.permute(0, 3, 1, 2).cpu()
             assert maxdiff(outs[plan], want) <= 2e-4, plan
-        for plan in range(100, 106):
+        for plan in range(100, 107):
             assert maxdiff(outs[plan], outs[100]) <= 1e-6                # every tile shape adds the K steps in the same order
     finally:
         ops.set_conv_math(prev_math)
@@ -608,13 +608,13 @@ def test_gemm_x3(dev, B, M, K, N):
     ref = torch.bmm(x.double(), w.double().transpose(1, 2))
     for act, slope in ((_lib.ACT_NONE, 0.0), (_lib.ACT_PRELU, 0.25)):
         want = ref if act == _lib.ACT_NONE else F.prelu(ref * scale.double() + bias.double(), torch.tensor([slope], dtype=torch.float64, device=dev))
-        for cfg in range(6):
+        for cfg in range(7):
             out = torch.full((B, M, N), float("nan"), device=dev)
             sb = (None, None) if act == _lib.ACT_NONE else (scale, bias)
             _lib.check(lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, P(sb[0]), P(sb[1]), None, 0, act, slope, 0, cfg, None, 0.0, st), "gemm_x3")
             assert float((out.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()), (act, cfg)
     assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K + 1, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 0, None, 0.0, st) == _lib.ARSEG_EINVAL
-    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 6, None, 0.0, st) == _lib.ARSEG_EINVAL
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 7, None, 0.0, st) == _lib.ARSEG_EINVAL
 
 
 @pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32), (3, 33, 70, 64, 128), (2, 7, 40, 64, 64)])

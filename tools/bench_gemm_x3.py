@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=int, default=-1)
-    ap.add_argument("--cfgs", default="0,1,2,3", help="tile_cfg values of the new kernel (4 + c / 8 + c / 12 + c, c in {0, 3}: ablation builds without DMA / fragment reads / both; wrong results)")
+    ap.add_argument("--cfgs", default="0,1,2,3,4,5,6", help="tile_cfg values of the new kernel (4 + c / 8 + c / 12 + c, c in {0, 3}: ablation builds without DMA / fragment reads / both; wrong results)")
     args = ap.parse_args()
     global CFGS
     CFGS = [int(c) for c in args.cfgs.split(",")]
