@@ -42,16 +42,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float *__restri
 // block = (bin, 16-channel chunk, n); 256 threads = 64 pixel lanes x 4 channel vectors; fixed-order LDS tree over the
 // pixel lanes (deterministic).  Small chunks keep many blocks in flight for the whole-image bins (1x1 pyramid level,
 // global mean / max), which are pure streaming reads.
-template <bool IS_MAX, int PL = 64>      // PL pixel lanes x 4 channel vectors: 256 threads, or 1024 for launches with few blocks
-__global__ __launch_bounds__(4 * PL) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
+template <bool IS_MAX, int PL = 64, int CV = 4>      // PL pixel lanes x CV channel vectors (16 bytes each): 256 threads, or 1024 for launches with few blocks
+__global__ __launch_bounds__(CV * PL) void window_reduce_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ out,
                                                                int out_ld, long long out_n_stride, int H, int W, int C, int oh, int ow,
                                                                int zb_n = 0, int zb_self = 0) {
-    __shared__ f32x4 red[PL][5];
+    __shared__ f32x4 red[PL][CV + 1];
     const int bin = blockIdx.x, by = bin / ow, bx = bin - by * ow, n = blockIdx.z;
     const int y0 = (by * H) / oh, y1 = ((by + 1) * H + oh - 1) / oh;
     const int x0 = (bx * W) / ow, x1 = ((bx + 1) * W + ow - 1) / ow;
-    const int cv = threadIdx.x & 3, pl = threadIdx.x >> 2;
-    const int c = blockIdx.y * 16 + cv * 4;
+    const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+    const int c = blockIdx.y * (CV * 4) + cv * 4;
     const int ww = x1 - x0, cnt = (y1 - y0) * ww;
     f32x4 acc = IS_MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
     if (c < C) {
@@ -749,8 +749,19 @@ extern "C" int arseg_adaptive_avgpool_blockrow_fwd(const float *in, int in_ld, f
     if (block < 0 || block >= n_blocks) return ARSEG_EINVAL;
     const int out_ld = n_blocks * C;
     if ((C & 3) || (in_ld & 3) || in_ld < C || (out_n_stride & 3) || out_n_stride < (long long)oh * ow * out_ld || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
-    const dim3 grid(oh * ow, arseg_cdiv(C, 16), N);
     float *o = out + (size_t)block * C;
+    if (!(C & 63) && (long long)oh * ow * (C / 64) * N >= 64) {
+        // 64 channels per workgroup: a pixel's share is 256 contiguous bytes (with 16 channels every pixel row of the map is fetched in 64-byte
+        // pieces by 32 different workgroups: 16-20 us per pyramid level of the 11-frame LR batch against 10-11.5).  Launches that would
+        // have fewer than 64 such workgroups (the 1x1 / 2x2 levels of a single keyframe) keep the narrow form: they need the parallelism more
+        const dim3 grid(oh * ow, C / 64, N);
+        if ((long long)grid.x * grid.y * grid.z < 512)
+            hipLaunchKernelGGL((window_reduce_kernel<false, 64, 16>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
+        else
+            hipLaunchKernelGGL((window_reduce_kernel<false, 16, 16>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
+        return arseg_launch_status();
+    }
+    const dim3 grid(oh * ow, arseg_cdiv(C, 16), N);
     if ((long long)grid.x * grid.y * grid.z < 256)
         hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
     else
