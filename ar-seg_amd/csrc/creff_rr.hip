@@ -22,6 +22,11 @@
 //
 // Arithmetic contract: as creff.hip (zero-padded unfold: keys / values outside the image are 0 and still take softmax mass).
 #include "creff_params.h"
+// cache policy of the p / logits stores: 2 = nontemporal (1.7 GB per 11-frame launch that nobody re-reads soon; keeps the XCD's L2 for the
+// overlapping gather of the keyframe feature: 242.4-243.9 -> 241.4 us per frame)
+#ifndef RR_PNT
+#define RR_PNT 2
+#endif
 #include "warp_math.h"
 
 namespace {
@@ -667,7 +672,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
             auto vrec = [&](int b) { return vbase + 384u * b + (((vsel >> b) & 1u) << 7); };
             auto epilogue = [&](int c, const f32x4 o) {       // o = p[query][16c + 4g .. +3]: store, then this chunk's share of the classifier
                 const unsigned off = p_off0 + (unsigned)c * p_step;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, (inq && RR_ON(9)) ? off : OOB, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, (inq && RR_ON(9)) ? off : OOB, 0, RR_PNT);
                 if (NB > 0 && RR_ON(13)) {
                     u32x2 oh, ol;
                     split4(o, oh, ol);
@@ -730,7 +735,7 @@ __global__ __launch_bounds__(NT) void creff_rr_kernel(const RRParams p) {
                 for (int i = 0; i < 4; ++i) {
                     const int cls = nb * 16 + 4 * g + i;
                     const unsigned off = l_off0 + (unsigned)cls * plane * 4u;
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls && RR_ON(14)) ? off : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls && RR_ON(14)) ? off : OOB, 0, RR_PNT);
                 }
         }
     }
