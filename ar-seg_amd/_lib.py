@@ -65,6 +65,7 @@ PROTOTYPES = {
     "arseg_wino43_input_split_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_wino43_output_fwd": (c_int, [_P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_float, _STREAM]),
     "arseg_upconv3x3_tap_gather_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
+    "arseg_upconv3x3_tap_gather_split_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_wino43_pack_weight_host": (c_int, [_P, c_int, c_int, _P]),
     "arseg_packed_k": (c_int, [c_int, c_int, c_int]),
     "arseg_pack_conv_weight_host": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -29,9 +29,12 @@ __device__ __forceinline__ float up_act(float v, int act, float slope) {
     }
 }
 
+// SPLIT: `out` is written as split rows (the operand format of arseg_gemm_x3_fwd, csrc/gemm_x3.hip; out_ld == C, C % 32 == 0) -- the output is
+// the next tap GEMM's activation operand (up_1 -> up_2) -- and the running |out| maximum feeds the operand range word.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void up2_tap_gather_kernel(const float *__restrict__ z, int z_ld, const float *__restrict__ scale,
                                                              const float *__restrict__ bias, float *__restrict__ out, int out_ld, int N, int h,
-                                                             int w, int C, int rs, int act, float slope) {
+                                                             int w, int C, int rs, int act, float slope, unsigned *range_flag, float range_limit) {
     const int Cv = C >> 2, strips = (h + rs - 1) / rs;
     const long long total = (long long)N * strips * w * Cv;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -72,7 +75,20 @@ __global__ __launch_bounds__(256) void up2_tap_gather_kernel(const float *__rest
     f32x4 Hm[3][2], H0[3][2], Hp[3][2];
     hrow(max(y0 - 1, 0), Hm);
     hrow(y0, H0);
-    float *on = out + (size_t)n * (2 * h) * (2 * w) * out_ld + c;
+    float *on = out + (size_t)n * (2 * h) * (2 * w) * out_ld + (SPLIT ? 0 : c);
+    float vmax = 0.f;
+    auto put = [&](size_t pix, const f32x4 v) {
+        if constexpr (SPLIT) {
+            unsigned h01, h23, l01, l23;
+            arseg_split_f16(v, h01, h23, l01, l23);
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+            unsigned char *o = reinterpret_cast<unsigned char *>(on + pix * out_ld) + (c >> 5) * 128 + (c & 31) * 2;
+            *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+            *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
+        } else {
+            *reinterpret_cast<f32x4 *>(on + pix * out_ld) = v;
+        }
+    };
     for (int y = y0; y < y1; ++y) {
         hrow(min(y + 1, h - 1), Hp);
         const bool vT = y >= 1, vB = y + 1 < h;
@@ -89,30 +105,49 @@ __global__ __launch_bounds__(256) void up2_tap_gather_kernel(const float *__rest
             o1 = o1 * sc + bi;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { o0[e] = up_act(o0[e], act, slope); o1[e] = up_act(o1[e], act, slope); }
-            *reinterpret_cast<f32x4 *>(on + ((size_t)(2 * y) * (2 * w) + 2 * x + b) * out_ld) = o0;
-            *reinterpret_cast<f32x4 *>(on + ((size_t)(2 * y + 1) * (2 * w) + 2 * x + b) * out_ld) = o1;
+            put((size_t)(2 * y) * (2 * w) + 2 * x + b, o0);
+            put((size_t)(2 * y + 1) * (2 * w) + 2 * x + b, o1);
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int b = 0; b < 2; ++b) { Hm[ky][b] = H0[ky][b]; H0[ky][b] = Hp[ky][b]; }
     }
+    if (SPLIT && range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
 }  // namespace
 
-extern "C" int arseg_upconv3x3_tap_gather_fwd(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N,
-                                              int h, int w, int Cout, int act, float prelu_slope, arseg_stream_t stream) {
+static int tap_gather(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N, int h, int w, int Cout, int act,
+                      float prelu_slope, bool split, void *range_flag, float range_limit, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(z); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w); ARSEG_CHECK_POS(Cout);
     if ((Cout & 3) || z_ld < 9 * Cout || (z_ld & 3) || out_ld < Cout || (out_ld & 3)) return ARSEG_EINVAL;
     if (!ARSEG_ALIGNED16(z) || !ARSEG_ALIGNED16(out) || (scale && !ARSEG_ALIGNED16(scale)) || (bias && !ARSEG_ALIGNED16(bias))) return ARSEG_EINVAL;
+    if (split && ((Cout & 31) || out_ld != Cout || (reinterpret_cast<uintptr_t>(range_flag) & 3))) return ARSEG_EINVAL;
     // strip length: the longest (fewest re-computed boundary rows: (rs + 2) / rs) that still gives every SIMD a couple of waves
     const long long per_strip = (long long)N * w * (Cout / 4);
     int rs = 16;
     while (rs > 2 && per_strip * ((h + rs - 1) / rs) < 2048ll * 64) rs >>= 1;
     const long long total = per_strip * ((h + rs - 1) / rs);
     if ((total + 255) / 256 >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
-    hipLaunchKernelGGL(up2_tap_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, arseg_stream(stream), z, z_ld, scale, bias,
-                       out, out_ld, N, h, w, Cout, rs, act, prelu_slope);
+    unsigned *rf = reinterpret_cast<unsigned *>(range_flag);
+    const float rl = range_limit > 0.0f ? range_limit : 65504.0f;
+    if (split)
+        hipLaunchKernelGGL(up2_tap_gather_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, arseg_stream(stream), z, z_ld, scale, bias,
+                           out, out_ld, N, h, w, Cout, rs, act, prelu_slope, rf, rl);
+    else
+        hipLaunchKernelGGL(up2_tap_gather_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, arseg_stream(stream), z, z_ld, scale, bias,
+                           out, out_ld, N, h, w, Cout, rs, act, prelu_slope, rf, rl);
     return arseg_launch_status();
+}
+
+extern "C" int arseg_upconv3x3_tap_gather_fwd(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N,
+                                              int h, int w, int Cout, int act, float prelu_slope, arseg_stream_t stream) {
+    return tap_gather(z, z_ld, scale, bias, out, out_ld, N, h, w, Cout, act, prelu_slope, false, nullptr, 0.0f, stream);
+}
+
+extern "C" int arseg_upconv3x3_tap_gather_split_fwd(const float *z, int z_ld, const float *scale, const float *bias, void *out_split, int N, int h,
+                                                    int w, int Cout, int act, float prelu_slope, void *range_flag, float range_limit,
+                                                    arseg_stream_t stream) {
+    return tap_gather(z, z_ld, scale, bias, reinterpret_cast<float *>(out_split), Cout, N, h, w, Cout, act, prelu_slope, true, range_flag, range_limit, stream);
 }

@@ -72,8 +72,10 @@ class PSPUpsample(HipModule):
     def _pack(self, device):
         return PackedConv.from_modules(self.conv[0], self.conv[1], _lib.ACT_PRELU, float(self.conv[2].weight.item()), device=device)
 
-    def forward_nhwc(self, x):
-        return ops.conv2d(x, self.packed(), up2=True)       # x2 bilinear upsample (F.upsample default) + conv + BN + PReLU
+    def forward_nhwc(self, x, out_split=False):
+        # x2 bilinear upsample (F.upsample default) + conv + BN + PReLU.  out_split: the only consumer is another PSPUpsample -- on the split-row
+        # route (x is an ops.SplitRows) the result is written as split rows too; otherwise the flag is ignored
+        return ops.conv2d(x, self.packed(), up2=True, out_split=out_split)
 
 
 class _PSPBase(HipModule):
@@ -106,7 +108,7 @@ class _PSPBase(HipModule):
         N, H, W, _ = x4.shape
         f, class_f = self.feats.forward_nhwc(x4)
         p = self.psp.forward_nhwc(f)            # drop_1 / drop_2: identity in eval
-        p = self.up_1.forward_nhwc(p)
+        p = self.up_1.forward_nhwc(p, out_split=True)
         p = self.up_2.forward_nhwc(p)
         p = self.up_3.forward_nhwc(p)
         pk = self.packed()

@@ -722,16 +722,17 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
             return _conv1x1_x3(x, pc, residual, out, out_split)
         if (up2 and gemm_x3_enabled() and _UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.dil == 1
                 and pc.cout % 4 == 0 and c_ % 32 == 0):
+            split_out = out_split and out is None and pc.cout % 32 == 0      # (the next layer is again a tap-decomposed upsample conv)
             if out is None:
                 out = torch.empty((n_, 2 * h_, 2 * w_, pc.cout), dtype=torch.float32, device=x.device)
             outer_tag = _layer_tag
             if _profile is not None and outer_tag is None:
                 _layer_tag = (n_, 2 * h_, 2 * w_, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, True, "taps(x3)", 2 * n_ * 4 * h_ * w_ * pc.cout * 9 * pc.cin)
             try:
-                _conv_up2_taps(x, pc, out)
+                _conv_up2_taps(x, pc, out, True, split_out)
             finally:
                 _layer_tag = outer_tag
-            return out
+            return SplitRows(out) if split_out else out
         return conv2d(x.float(), pc, residual, out, tile_cfg, split_k, up2, out_split)
     if is16(x):
         return _conv2d16(x, pc, residual, out, up2, tile_cfg, split_k)
@@ -1072,18 +1073,24 @@ _UP2_TAPS = config.conv_up2_taps
 _GEMM_X3 = config.conv_gemm_x3
 
 
-def _conv_up2_taps(x_low, pc, out, record=True):
+def _conv_up2_taps(x_low, pc, out, record=True, out_split=False):
     """conv3x3(pad 1) of the x2 bilinear upsample of ``x_low`` by tap decomposition (csrc/upconv.hip): one 1x1 conv at low resolution
     with the nine taps stacked along the output channels, then the gather that samples the nine planes at the shifted positions of the
-    upsampled image and applies the epilogue of ``pc``."""
+    upsampled image and applies the epilogue of ``pc``.  out_split: the gather writes ``out`` (contiguous, Cout % 32 == 0) as split rows."""
     lib = _lib.load()
     n, h, w, _ = x_low.shape
     z = conv2d(x_low, pc.taps())
-    args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, pc.cout, pc.act, pc.slope, _stream())
-    if record:
-        _launch("up2_tap_gather", lib.arseg_upconv3x3_tap_gather_fwd, *args)
+    if out_split:
+        rw = _range_word(out.device) if _RANGE_MODE == "device" else None
+        fn, name = lib.arseg_upconv3x3_tap_gather_split_fwd, "up2_tap_gather"
+        args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), n, h, w, pc.cout, pc.act, pc.slope, _ptr(rw), 65504.0, _stream())
     else:
-        check(lib.arseg_upconv3x3_tap_gather_fwd(*args), "up2_tap_gather")
+        fn, name = lib.arseg_upconv3x3_tap_gather_fwd, "up2_tap_gather"
+        args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, pc.cout, pc.act, pc.slope, _stream())
+    if record:
+        _launch(name, fn, *args)
+    else:
+        check(fn(*args), name)
 
 
 def _tune_conv(launch, pc, m, allow_patch=True):

@@ -271,6 +271,11 @@ int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int 
  * its transformed operand (9x the low-resolution input) and without its rounding amplification.  Cout % 4 == 0, 16-byte aligned. */
 int arseg_upconv3x3_tap_gather_fwd(const float *z, int z_ld, const float *scale, const float *bias, float *out, int out_ld, int N, int h,
                                    int w, int Cout, int act, float prelu_slope, arseg_stream_t stream);
+/* The same gather with its output written as split rows [N, 2h, 2w, Cout] (Cout % 32 == 0; the operand format of arseg_gemm_x3_fwd): the next
+ * layer is again a tap-decomposed PSPUpsample whose low-resolution GEMM stages them by LDS-DMA (up_1 -> up_2).  range_flag / range_limit as in
+ * arseg_split_rows_fwd. */
+int arseg_upconv3x3_tap_gather_split_fwd(const float *z, int z_ld, const float *scale, const float *bias, void *out_split, int N, int h, int w,
+                                         int Cout, int act, float prelu_slope, void *range_flag, float range_limit, arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
 
 /* Host-side weight preparation (the "weight packer"; CPU pointers).

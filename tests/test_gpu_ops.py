@@ -567,6 +567,16 @@ def test_conv_chain_split_rows(dev, N, h, w, Cin, Cmid, Cout):
         want = F.prelu(F.conv2d(up, w3.double(), b3.double(), padding=1), torch.tensor([0.25], dtype=torch.float64)).float()
         got = ops.conv2d(mid, pc3, up2=True)
         assert maxdiff(got.permute(0, 3, 1, 2), want) <= 5e-5
+        # up_1 -> up_2: the gather writes split rows as well and a second tap-decomposed upsample conv consumes them
+        if Cout % 32 == 0:
+            w4 = rnd(406, 32, Cout, 3, 3, scale=float(np.sqrt(2.0 / (9 * Cout))))
+            pc4 = PackedConv(w4, None, None, 1, 1, 1, _lib.ACT_PRELU, 0.1, dev)
+            mid2 = ops.conv2d(mid, pc3, up2=True, out_split=True)
+            assert isinstance(mid2, ops.SplitRows) and maxdiff(mid2.float(), got) <= 1e-6 * float(got.abs().max())
+            up2_ = F.interpolate(want.double(), scale_factor=2.0, mode="bilinear", align_corners=False)
+            want2 = F.prelu(F.conv2d(up2_, w4.double(), None, padding=1), torch.tensor([0.1], dtype=torch.float64)).float()
+            got2 = ops.conv2d(mid2, pc4, up2=True)
+            assert maxdiff(got2.permute(0, 3, 1, 2), want2) <= 1e-4
         got_fp32_in = ops.conv2d(plain, pc3, up2=True)             # whatever plan the tuner picks for the fp32 input
         assert maxdiff(got_fp32_in, got) <= 1e-4
         # a consumer without a split-row route (3x3 at the same resolution) reads the fp32 form
