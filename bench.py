@@ -182,7 +182,8 @@ def main():
     ap.add_argument("--variant-steps", type=int, default=9)
     ap.add_argument("--conv-layers", metavar="FILE", help="also write the per-layer conv table (shape, plan, us, TFLOP/s, fraction of the MFMA peak) as JSON")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
-    ap.add_argument("--streams", type=int, default=3, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
+    ap.add_argument("--streams", type=int, default=6, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
+    ap.add_argument("--joined-graph", action="store_true", help="capture the lanes into ONE graph with a join per replay (the round-2 executor) instead of one graph per lane")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured HIP graph (N = 1 only)")
     ap.add_argument("--conv-math", choices=["f16x3", "f32", "f16"], default="f16x3",
                     help="MFMA back end of the fp32 conv GEMMs: f16x3 = split-fp16 emulation (3 fp16 MFMAs, fp32 accumulate), f32 = fp32 MFMA")
@@ -295,7 +296,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     if world == 1 and not args.no_graph:
         from arseg_amd.executor import GopGraph
         with torch.cuda.stream(streams[0]):
-            gop_graph = GopGraph([step] * len(streams), warmup=1)
+            gop_graph = GopGraph([step] * len(streams), warmup=1, independent=not args.joined_graph)
         torch.cuda.synchronize()
 
     def run_steps(k):
@@ -371,7 +372,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
         "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
                                        "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
-        "streams": len(streams), "executor": "hip-graph replay (%d GOP steps per replay on forked streams)" % len(streams) if gop_graph is not None else "eager launches",
+        "streams": len(streams), "executor": ("hip-graph replay (%d lanes, one graph per lane on its own stream)" if not args.joined_graph else "hip-graph replay (%d GOP steps per replay on forked streams)") % len(streams) if gop_graph is not None else "eager launches",
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},

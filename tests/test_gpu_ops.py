@@ -993,3 +993,33 @@ def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout):
             assert maxdiff(logits, lg) <= 2 * tol
         else:
             assert logits is None
+
+
+@pytest.mark.parametrize("independent", [False, True])
+def test_gop_graph_lanes(dev, independent):
+    """executor.GopGraph: lanes captured into one joined graph or into one graph per lane on its own stream; replays reproduce the eager result
+    bit for bit and pick up inputs refilled in place."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.executor import GopGraph
+    from arseg_amd.packing import PackedConv
+
+    x = rnd(900, 2, 24, 40, 64).to(dev)
+    w = rnd(901, 64, 64, 3, 3, scale=0.05)
+    pc1 = PackedConv(w, None, None, 1, 1, 1, _lib.ACT_RELU, 0.0, dev)
+    pc2 = PackedConv(rnd(902, 32, 64, 1, 1, scale=0.1), None, None, 1, 0, 1, _lib.ACT_NONE, 0.0, dev)
+
+    def step():
+        return ops.conv2d(ops.conv2d(x, pc1), pc2)
+
+    want = step().clone()
+    g = GopGraph([step] * 3, warmup=1, independent=independent)
+    for _ in range(2):
+        outs = g.replay()
+        g.synchronize()
+        torch.cuda.synchronize()
+        assert len(outs) == 3 and all(torch.equal(o, want) for o in outs)
+    x.mul_(2.0)                                  # inputs are read from fixed tensors: refill in place, replay
+    want2 = step().clone()
+    outs = g.replay()
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want2) for o in outs) and not torch.equal(want2, want)
