@@ -36,6 +36,7 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--sets", type=int, default=1, help="buffer sets used in rotation (8: cold, every launch reads from HBM)")
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device("cuda:0")
@@ -43,15 +44,26 @@ def main():
     tot_i = tot_o = 0.0
     for N, H, W, C, dil in SHAPES:
         T = lib.arseg_wino43_tiles(N, H, W, dil)
-        x = torch.randn(N, H, W, C, device=dev)
-        res = torch.randn(N, H, W, C, device=dev)
-        out = torch.empty(N, H, W, C, device=dev)
-        V = torch.empty(36, T, C, device=dev)
-        M = torch.randn(36, T, C, device=dev)
+        # --sets buffer sets in rotation: with one set the tensors stay in the 256 MB Infinity Cache (5-6 TB/s); in a GOP step they come from HBM
+        S = args.sets
+        x = [torch.randn(N, H, W, C, device=dev) for _ in range(S)]
+        res = [torch.randn(N, H, W, C, device=dev) for _ in range(S)]
+        out = [torch.empty(N, H, W, C, device=dev) for _ in range(S)]
+        V = [torch.empty(36, T, C, device=dev) for _ in range(S)]
+        M = [torch.randn(36, T, C, device=dev) for _ in range(S)]
         sc, bi = torch.ones(C, device=dev), torch.zeros(C, device=dev)
-        # several buffers in rotation so that the timing is not an Infinity-Cache hit rate of one 100 MB tensor
-        ti = timeit(lambda: _lib.check(lib.arseg_wino43_input_split_fwd(P(x), C, P(V), N, H, W, C, dil, 0, 0.0625, None, 0.0, st), "in"), args.reps)
-        to = timeit(lambda: _lib.check(lib.arseg_wino43_output_fwd(P(M), P(sc), P(bi), P(res), C, P(out), C, N, H, W, C, dil, _lib.ACT_RELU, 0.0, 16.0, st), "out"), args.reps)
+        it = [0]
+
+        def run_in():
+            k = it[0] = (it[0] + 1) % S
+            _lib.check(lib.arseg_wino43_input_split_fwd(P(x[k]), C, P(V[k]), N, H, W, C, dil, 0, 0.0625, None, 0.0, st), "in")
+
+        def run_out():
+            k = it[0] = (it[0] + 1) % S
+            _lib.check(lib.arseg_wino43_output_fwd(P(M[k]), P(sc), P(bi), P(res[k]), C, P(out[k]), C, N, H, W, C, dil, _lib.ACT_RELU, 0.0, 16.0, st), "out")
+
+        ti = timeit(run_in, args.reps)
+        to = timeit(run_out, args.reps)
         bi_ = (N * H * W * C * 4 + 36 * T * C * 4) / 1e3
         bo_ = (2 * N * H * W * C * 4 + 36 * T * C * 4 + N * H * W * C * 4 * 0) / 1e3
         print(f"N{N} {H}x{W} C{C} d{dil}: input {ti:7.1f} us ({bi_ / ti / 1e3:5.2f} TB/s)   output {to:7.1f} us ({(bo_ + N * H * W * C * 4 / 1e3) / to / 1e3:5.2f} TB/s)", flush=True)
