@@ -12,6 +12,8 @@ A "step" is one GOP per rank, i.e. one pass of the hot path over one batch of sy
     MV resize + warp, fused CReFF + classifier + log-softmax]
 All inputs (frames, int16 MV maps, weights) are resident in HBM before the timed region.  `value` counts the
 non-keyframes only, while the keyframe's HR forward and the exchange are inside the timed region (nothing skipped).
+Consecutive GOPs are independent; `--streams` of them (default 6) are in flight at a time, each on its own HIP stream (N = 1: one captured
+HIP graph per lane, arseg_amd/executor.py), and exactly K steps are enqueued and completed inside the timed region.
 
 Arithmetic: fp32 tensors end to end.  The convolution GEMMs are evaluated on the fp16 matrix cores with every fp32 operand
 split into hi + lo fp16 (22 significant bits) and three MFMAs per product, fp32 accumulation (`--conv-math f16x3`, default;
