@@ -42,3 +42,50 @@ def test_range_word_is_inert_without_a_gpu():
     from arseg_amd import ops
 
     assert ops.range_tripped(device="cuda:0") is False          # no conv has run: no word exists, nothing is read
+
+
+def test_gemm_x3_knob(monkeypatch):
+    """ARSEG_CONV_GEMM_X3 = 1 | wino | 0 and what each enables: the split-row chain needs the knob fully on, the f16x3 back end and the device
+    (or no) range guard -- under the host-synchronising guard or another back end the producers keep writing fp32 tensors."""
+    from arseg_amd import ops
+
+    for v, want in (("1", True), ("wino", "wino"), ("0", False)):
+        monkeypatch.setenv("ARSEG_CONV_GEMM_X3", v)
+        assert ops.Config.from_env().conv_gemm_x3 == want
+    monkeypatch.delenv("ARSEG_CONV_GEMM_X3")
+    assert ops.Config.from_env().conv_gemm_x3 is True
+    prev = ops.configure(conv_gemm_x3=True, conv_math="f16x3", conv_range_guard="device")
+    try:
+        assert ops.gemm_x3_enabled()
+        for kw in ({"conv_gemm_x3": "wino"}, {"conv_gemm_x3": False}, {"conv_math": "f32"}, {"conv_range_guard": "host"}):
+            old = ops.configure(**kw)
+            assert not ops.gemm_x3_enabled(), kw
+            ops.configure(**old)
+        assert ops.gemm_x3_enabled()
+    finally:
+        ops.configure(**prev)
+
+
+def test_split_rows_layout_matches_host_packer():
+    """ops.SplitRows (the activation operand format of arseg_gemm_x3_fwd) is the f16x3 weight format of arseg_split_weight_f16x3_host: per 32
+    values 32 hi halves then 32 lo halves, hi + lo = x to 22 bits.  Checked on the CPU with the host packer and SplitRows.float()."""
+    import ctypes
+
+    import numpy as np
+    import torch
+
+    from arseg_amd import _lib, ops
+
+    lib = _lib.load()
+    g = np.random.Generator(np.random.PCG64(7))
+    rows, K = 24, 96
+    x = (g.standard_normal((rows, K)) * np.exp(g.standard_normal((rows, 1)))).astype(np.float32)
+    out = np.empty_like(x)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)      # noqa: E731
+    _lib.check(lib.arseg_split_weight_f16x3_host(P(x), rows, K, P(out), None), "split_weight_f16x3")
+    halves = out.view(np.float16).reshape(rows, K // 32, 2, 32).astype(np.float32)
+    hi, lo = halves[:, :, 0].reshape(rows, K), halves[:, :, 1].reshape(rows, K)
+    assert np.all(np.abs(hi) <= np.abs(x)) and np.all(np.abs(hi + lo - x) <= 2.0 ** -20 * np.abs(x) + 2.0 ** -24)      # (the host packer truncates both halves)
+    sr = ops.SplitRows(torch.from_numpy(out).reshape(2, 3, 4, K))
+    assert sr.shape == (2, 3, 4, K)
+    assert torch.equal(sr.float(), torch.from_numpy(hi + lo).reshape(2, 3, 4, K))
