@@ -60,6 +60,8 @@ PROTOTYPES = {
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
     "arseg_split_rows_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_gemm_x3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, c_float, _STREAM]),
+    "arseg_gemm_x3_cat_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P,
+                              c_int, c_float, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_wino43_tiles": (c_int64, [c_int, c_int, c_int, c_int]),
     "arseg_wino43_input_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
     "arseg_wino43_input_split_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_float, _STREAM]),

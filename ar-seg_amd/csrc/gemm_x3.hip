@@ -27,6 +27,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GX3Params {
     const unsigned char *X, *W;
+    const unsigned char *X2, *W2;     // K concatenation: K steps >= K / 32 read these (K2 values per row), e.g. [features | interpolation matrix] x
+    int K2;                           //   [bottleneck weights ; per-image pyramid terms]: out = x.w^T + x2.w2^T  (0: none)
+    unsigned x2_bytes, w2_bytes;
+    long long x2_bs, w2_bs;
     float *C;
     const float *scale, *bias, *res;
     int M, N, K, ldc, res_ld, out_split;
@@ -76,31 +80,42 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     const int wm = wave / NWN, wn = wave % NWN;
     const u32x4 x_rsrc = make_rsrc(p.X + (size_t)b * p.x_bs, p.x_bytes);
     const u32x4 w_rsrc = make_rsrc(p.W + (size_t)b * p.w_bs, p.w_bytes);
-    const unsigned ld = (unsigned)p.K * 4u;
+    const unsigned ld = (unsigned)p.K * 4u, ld2 = (unsigned)p.K2 * 4u;
+    const u32x4 x2_rsrc = make_rsrc(p.K2 ? p.X2 + (size_t)b * p.x2_bs : p.X, p.K2 ? p.x2_bytes : 0u);
+    const u32x4 w2_rsrc = make_rsrc(p.K2 ? p.W2 + (size_t)b * p.w2_bs : p.W, p.K2 ? p.w2_bytes : 0u);
+    const int k1 = p.K >> 5;
 
     // DMA: lane (r8, pos) of instruction j fills LDS row wave*rows + 8j + r8, 16-byte position pos, with source slot pos ^ g(row)
     const int r8 = lane >> 3, pos = lane & 7;
-    unsigned xsrc[XI], wsrc[WI];
+    unsigned xsrc[XI], wsrc[WI], xsrc2[XI], wsrc2[WI];
 #pragma unroll
     for (int j = 0; j < XI; ++j) {
         const int row = wave * (BM / NW) + j * 8 + r8;
-        xsrc[j] = (unsigned)min(m0 + row, p.M - 1) * ld + (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+        const unsigned gr = (unsigned)min(m0 + row, p.M - 1), sl = (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+        xsrc[j] = gr * ld + sl;
+        xsrc2[j] = gr * ld2 + sl;
     }
 #pragma unroll
     for (int j = 0; j < WI; ++j) {
         const int row = wave * (BN / NW) + j * 8 + r8;
-        wsrc[j] = (unsigned)min(n0 + row, p.N - 1) * ld + (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+        const unsigned gr = (unsigned)min(n0 + row, p.N - 1), sl = (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
+        wsrc[j] = gr * ld + sl;
+        wsrc2[j] = gr * ld2 + sl;
     }
     const unsigned lds0 = lds_addr(smem);
     auto issue_x = [&](int kt, int st) {
-        const unsigned kb = (unsigned)kt * 128u, base = lds0 + (unsigned)st * STAGE;
+        const bool second = kt >= k1;                  // (uniform) the K steps of the concatenated second operand pair
+        const unsigned kb = (unsigned)(second ? kt - k1 : kt) * 128u, base = lds0 + (unsigned)st * STAGE;
+        const u32x4 rs = second ? x2_rsrc : x_rsrc;
 #pragma unroll
-        for (int j = 0; j < XI; ++j) dma16_buf(x_rsrc, xsrc[j] + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
+        for (int j = 0; j < XI; ++j) dma16_buf(rs, (second ? xsrc2[j] : xsrc[j]) + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
     };
     auto issue_w = [&](int kt, int st) {
-        const unsigned kb = (unsigned)kt * 128u, base = lds0 + (unsigned)st * STAGE;
+        const bool second = kt >= k1;
+        const unsigned kb = (unsigned)(second ? kt - k1 : kt) * 128u, base = lds0 + (unsigned)st * STAGE;
+        const u32x4 rs = second ? w2_rsrc : w_rsrc;
 #pragma unroll
-        for (int j = 0; j < WI; ++j) dma16_buf(w_rsrc, wsrc[j] + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
+        for (int j = 0; j < WI; ++j) dma16_buf(rs, (second ? wsrc2[j] : wsrc[j]) + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
     };
 
     // fragment reads: lane (i16, kq) reads row i16 of a 16-row fragment, source slot kq (hi) / 4 + kq (lo) -> position slot ^ (i16 >> 1)
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
         }
     };
 
-    const int nk = p.K >> 5;
+    const int nk = k1 + (p.K2 >> 5);
     issue_x(0, 0);
     issue_w(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -350,20 +365,26 @@ extern "C" int arseg_split_rows_fwd(const float *in, long long in_ld, void *out,
     return arseg_launch_status();
 }
 
-extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
-                                 long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
-                                 const float *bias, const float *residual, int res_ld, int act, float prelu_slope, int out_split, int tile_cfg,
-                                 void *range_flag, float range_limit, arseg_stream_t stream) {
+static int gemm_x3(const void *x_split, const void *w_split, const void *x2_split, const void *w2_split, float *out, int M, int N, int K, int K2,
+                   int out_ld, int batch, long long x_batch_stride, long long w_batch_stride, long long x2_batch_stride, long long w2_batch_stride,
+                   long long out_batch_stride, const float *scale, const float *bias, const float *residual, int res_ld, int act,
+                   float prelu_slope, int out_split, int tile_cfg, void *range_flag, float range_limit, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(x_split); ARSEG_CHECK_PTR(w_split); ARSEG_CHECK_PTR(out);
     if (M <= 0 || N <= 0 || K <= 0 || (K & 31) || (N & 3) || out_ld < N || (out_ld & 3) || batch <= 0) return ARSEG_EINVAL;
     if (!ARSEG_ALIGNED16(x_split) || !ARSEG_ALIGNED16(w_split) || !ARSEG_ALIGNED16(out) || (x_batch_stride & 15) || (w_batch_stride & 15) || (out_batch_stride & 3))
         return ARSEG_EINVAL;
+    if (K2 < 0 || (K2 & 31) || (K2 && (!x2_split || !w2_split || !ARSEG_ALIGNED16(x2_split) || !ARSEG_ALIGNED16(w2_split) || (x2_batch_stride & 15) || (w2_batch_stride & 15))))
+        return ARSEG_EINVAL;
     if ((scale && !ARSEG_ALIGNED16(scale)) || (bias && !ARSEG_ALIGNED16(bias))) return ARSEG_EINVAL;
     if (residual && (batch > 1 || res_ld < N || (res_ld & 3) || !ARSEG_ALIGNED16(residual))) return ARSEG_EINVAL;
     if (out_split && ((N & 31) || out_ld != N)) return ARSEG_EINVAL;
-    if ((long long)M * K * 4 >= (1ll << 32) || (long long)N * K * 4 >= (1ll << 32)) return ARSEG_EUNSUPPORTED;      // 32-bit buffer offsets
+    const int Kmax = K > K2 ? K : K2;
+    if ((long long)M * Kmax * 4 >= (1ll << 32) || (long long)N * Kmax * 4 >= (1ll << 32)) return ARSEG_EUNSUPPORTED;      // 32-bit buffer offsets
     GX3Params p;
     p.X = reinterpret_cast<const unsigned char *>(x_split); p.W = reinterpret_cast<const unsigned char *>(w_split); p.C = out;
+    p.X2 = reinterpret_cast<const unsigned char *>(x2_split); p.W2 = reinterpret_cast<const unsigned char *>(w2_split); p.K2 = K2;
+    p.x2_bytes = (unsigned)((long long)M * K2 * 4); p.w2_bytes = (unsigned)((long long)N * K2 * 4);
+    p.x2_bs = batch > 1 ? x2_batch_stride : 0; p.w2_bs = batch > 1 ? w2_batch_stride : 0;
     p.scale = scale; p.bias = bias; p.res = residual; p.res_ld = res_ld; p.out_split = out_split ? 1 : 0; p.M = M; p.N = N; p.K = K; p.ldc = out_ld;
     p.x_bytes = (unsigned)((long long)M * K * 4); p.w_bytes = (unsigned)((long long)N * K * 4);
     p.x_bs = batch > 1 ? x_batch_stride : 0; p.w_bs = batch > 1 ? w_batch_stride : 0; p.c_bs = batch > 1 ? out_batch_stride : 0;
@@ -381,4 +402,22 @@ extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float
         case 4: return launch_cfg<4>(p, tile_cfg, hs);
         default: return ARSEG_EINVAL;
     }
+}
+
+extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
+                                 long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
+                                 const float *bias, const float *residual, int res_ld, int act, float prelu_slope, int out_split, int tile_cfg,
+                                 void *range_flag, float range_limit, arseg_stream_t stream) {
+    return gemm_x3(x_split, w_split, nullptr, nullptr, out, M, N, K, 0, out_ld, batch, x_batch_stride, w_batch_stride, 0, 0, out_batch_stride, scale,
+                   bias, residual, res_ld, act, prelu_slope, out_split, tile_cfg, range_flag, range_limit, stream);
+}
+
+extern "C" int arseg_gemm_x3_cat_fwd(const void *x_split, const void *w_split, const void *x2_split, const void *w2_split, float *out, int M, int N,
+                                     int K, int K2, int out_ld, int batch, long long x_batch_stride, long long w_batch_stride,
+                                     long long x2_batch_stride, long long w2_batch_stride, long long out_batch_stride, const float *scale,
+                                     const float *bias, int act, float prelu_slope, int out_split, int tile_cfg, void *range_flag,
+                                     float range_limit, arseg_stream_t stream) {
+    if (K2 <= 0) return ARSEG_EINVAL;
+    return gemm_x3(x_split, w_split, x2_split, w2_split, out, M, N, K, K2, out_ld, batch, x_batch_stride, w_batch_stride, x2_batch_stride, w2_batch_stride,
+                   out_batch_stride, scale, bias, nullptr, 0, act, prelu_slope, out_split, tile_cfg, range_flag, range_limit, stream);
 }

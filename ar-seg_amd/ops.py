@@ -1165,6 +1165,62 @@ def psp_pool_matrix(x: torch.Tensor, sizes) -> torch.Tensor:
     return out
 
 
+_psp_interp = {}
+
+
+def psp_bottleneck_x3(feats: torch.Tensor, t: torch.Tensor, pc, sizes, out_split: bool = True):
+    """PSPModule's folded bottleneck (model/pspnet.py:14-31) as ONE GEMM:  relu(W_f f + b + sum_s upsample(t_s))  with the pyramid sum written as
+    B . T -- B [H*W, 64] the bilinear interpolation matrix of the pooled rows (built once per shape by running psp_prior_sum on an identity, so it
+    holds exactly the weights that kernel applies), T the per-image pyramid terms -- and concatenated along K of the bottleneck GEMM
+    (arseg_gemm_x3_cat_fwd): [f | B] . [W_f ; T]^T.  The 92 MB prior tensor (written by one kernel, read back as a residual by the next) is
+    gone: two more K steps.  feats [N,H,W,C] fp32, t [N, rows, C_out] (rows = sum s^2 <= 64); returns SplitRows / tensor [N,H,W,C_out]."""
+    lib = _lib.load()
+    N, H, W, C = feats.shape
+    rows, Cout, dev = t.shape[1], pc.cout, feats.device
+    key = (dev.index, H, W, tuple(sizes))
+    B = _psp_interp.get(key)
+    if B is None:
+        eye = torch.zeros((1, rows, 64), dtype=torch.float32, device=dev)
+        eye[0, torch.arange(rows), torch.arange(rows)] = 1.0
+        B = _psp_interp[key] = split_rows(psp_prior_sum(eye, sizes, H, W))          # [1,H,W,64] split rows, shared by the batch
+    fac = pc.__dict__.get("_x3_unscale")
+    if fac is None:
+        fac = pc.__dict__["_x3_unscale"] = (1.0 / pc.scale_h3).contiguous()          # the epilogue multiplies the accumulator by scale_h3
+    w2 = torch.zeros((N, Cout, 1, 64), dtype=torch.float32, device=dev)
+    w2[:, :, 0, :rows] = (t.reshape(N, rows, Cout) * fac).transpose(1, 2)
+    w2s = split_rows(w2)
+    xs = split_rows(feats)
+    out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    rw = _range_word(dev) if (out_split and _RANGE_MODE == "device") else None
+
+    def run(c, rec):
+        args = (_ptr(xs.t), _ptr(pc.w_h3), _ptr(B.t), _ptr(w2s.t), _ptr(out), H * W, Cout, C, 64, Cout, N, H * W * C * 4, 0, 0, Cout * 64 * 4, H * W * Cout,
+                _ptr(pc.scale_h3), _ptr(pc.bias), pc.act, pc.slope, 1 if out_split else 0, c, _ptr(rw), 65504.0, _stream())
+        if rec:
+            _launch("conv2d", lib.arseg_gemm_x3_cat_fwd, *args, flops=2 * N * H * W * (C + 64) * Cout)
+        else:
+            check(lib.arseg_gemm_x3_cat_fwd(*args), "gemm_x3_cat")
+
+    pkey = ("x3cat", dev.index, N, H * W, C, Cout, bool(out_split))
+    cfg = _conv_plans.get(pkey)
+    if cfg is None:
+        best_t = float("inf")
+        for c in range(7):
+            tm = _time(lambda: run(c, False))
+            if tm < best_t:
+                cfg, best_t = c, tm
+        _conv_plans[pkey] = cfg
+    global _layer_tag
+    outer = _layer_tag
+    if _profile is not None and outer is None:
+        _layer_tag = (N, H, W, C, Cout, 1, 1, 1, False, "x3(cat, split out)", 2 * N * H * W * C * Cout)
+    try:
+        run(cfg, True)
+    finally:
+        _layer_tag = outer
+    return SplitRows(out) if out_split else out
+
+
 def psp_prior_sum(t: torch.Tensor, sizes, H: int, W: int) -> torch.Tensor:
     """t [N, sum(s^2), C] (per-level maps after the folded 1x1 convs) -> [N,H,W,C] sum of bilinear upsamples."""
     _need_gpu(t)

@@ -261,6 +261,14 @@ int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int 
                       long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
                       const float *bias, const float *residual, int res_ld, int act, float prelu_slope, int out_split, int tile_cfg,
                       void *range_flag, float range_limit, arseg_stream_t stream);
+/* The same GEMM over a K-concatenated operand pair: out = act(scale * (x . w^T + x2 . w2^T) + bias), x2 [batch][M][K2], w2 [batch][N][K2] split rows
+ * with their own batch strides (0 = shared by the batch).  The folded PSP pyramid uses it (model/pspnet.py:14-31): x2 = the bilinear
+ * interpolation matrix of the pooled rows (shared), w2 = the per-image pyramid terms, so that sum_s upsample(...) is two more K steps of the
+ * bottleneck GEMM instead of a 92 MB tensor written by one kernel and read back as a residual by the next. */
+int arseg_gemm_x3_cat_fwd(const void *x_split, const void *w_split, const void *x2_split, const void *w2_split, float *out, int M, int N, int K,
+                          int K2, int out_ld, int batch, long long x_batch_stride, long long w_batch_stride, long long x2_batch_stride,
+                          long long w2_batch_stride, long long out_batch_stride, const float *scale, const float *bias, int act,
+                          float prelu_slope, int out_split, int tile_cfg, void *range_flag, float range_limit, arseg_stream_t stream);
 
 /* conv3x3 (pad 1, stride 1) of a x2 bilinear (align_corners=False) upsample -- PSPUpsample, /root/reference/model/pspnet.py:43-46 --
  * by tap decomposition: since a 1x1 conv commutes with a per-channel resize, conv3x3(Up(x)) = sum_t shift_t(Up(W_t x)).  The caller

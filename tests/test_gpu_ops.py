@@ -995,6 +995,33 @@ def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout):
             assert logits is None
 
 
+@pytest.mark.parametrize("B,M,K,K2,N", [(3, 300, 96, 32, 36), (11, 2048, 512, 64, 1024), (1, 77, 32, 64, 64)])
+def test_gemm_x3_cat(dev, B, M, K, K2, N):
+    """arseg_gemm_x3_cat_fwd: out = act(scale (x.w^T + x2.w2^T) + bias) with a batch-strided x / shared w and a shared x2 / batch-strided w2 (the
+    folded PSP bottleneck's operand pattern), every tile_cfg, against fp64."""
+    import ctypes
+
+    from arseg_amd import _lib
+
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)      # noqa: E731
+    x, w = rnd(500, B, M, K).to(dev), rnd(501, N, K, scale=0.1).to(dev)
+    x2, w2 = rnd(502, M, K2).abs().to(dev), rnd(503, B, N, K2, scale=0.3).to(dev)
+    scale, bias = rnd(504, N).abs().add(0.5).to(dev), rnd(505, N).to(dev)
+    sp = {}
+    for name, a in (("x", x), ("w", w), ("x2", x2), ("w2", w2)):
+        sp[name] = torch.empty_like(a)
+        _lib.check(lib.arseg_split_rows_fwd(P(a), a.shape[-1], P(sp[name]), a.numel() // a.shape[-1], a.shape[-1], 1.0, None, 0.0, st), "split")
+    want = torch.relu((torch.einsum("bmk,nk->bmn", x.double(), w.double()) + torch.einsum("mk,bnk->bmn", x2.double(), w2.double())) * scale.double() + bias.double())
+    for cfg in range(7):
+        out = torch.full((B, M, N), float("nan"), device=dev)
+        _lib.check(lib.arseg_gemm_x3_cat_fwd(P(sp["x"]), P(sp["w"]), P(sp["x2"]), P(sp["w2"]), P(out), M, N, K, K2, N, B, M * K * 4, 0, 0, N * K2 * 4, M * N,
+                                             P(scale), P(bias), _lib.ACT_RELU, 0.0, 0, cfg, None, 0.0, st), "gemm_x3_cat")
+        assert float((out.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()), cfg
+    assert lib.arseg_gemm_x3_cat_fwd(P(sp["x"]), P(sp["w"]), None, None, P(out), M, N, K, K2, N, B, 0, 0, 0, 0, 0, None, None, 0, 0.0, 0, 0, None, 0.0, st) == _lib.ARSEG_EINVAL
+
+
 @pytest.mark.parametrize("independent", [False, True])
 def test_gop_graph_lanes(dev, independent):
     """executor.GopGraph: lanes captured into one joined graph or into one graph per lane on its own stream; replays reproduce the eager result
