@@ -382,7 +382,8 @@ __global__ __launch_bounds__(256) void head_kernel(const float *__restrict__ p, 
 // 256-byte rows with a lane stride of 256 bytes and re-reads the weights from LDS per pixel: 108 us for the 512x1024x64 keyframe feature
 // against ~35 us of memory time).  K order: lane half lh covers channels [lh*C/2, (lh+1)*C/2) so a lane's operands are contiguous (one
 // ds_read_b128 per 4 MFMAs and operand).  A lane owns one pixel and 16 of the 32 class rows; LogSoftmax needs one cross-half exchange.
-__global__ __launch_bounds__(256) void head_mfma_kernel(const float *__restrict__ p, int p_ld, const float *__restrict__ wf,
+template <int NPC>      // 16-byte pieces of a 32-pixel tile per lane: C / 8 (8 at C = 64, 16 at C = 128)
+__global__ __launch_bounds__(256, NPC == 8 ? 3 : 2) void head_mfma_kernel(const float *__restrict__ p, int p_ld, const float *__restrict__ wf,
                                                         const float *__restrict__ bf, float *__restrict__ logits, int N, int HW, int C,
                                                         int n_cls, int log_softmax) {
     extern __shared__ __attribute__((aligned(16))) float hsm[];
@@ -399,16 +400,29 @@ __global__ __launch_bounds__(256) void head_mfma_kernel(const float *__restrict_
     __syncthreads();
     const long long total = (long long)N * HW, ntile = (total + 31) / 32;
     const int npc = (32 * c4n + 63) / 64;                   // 16-byte pieces of a tile per lane (8 at C = 64)
-    for (long long tile = (long long)blockIdx.x * 4 + (tid >> 6); tile < ntile; tile += (long long)gridDim.x * 4) {
+    // The next tile of the wave is requested before the current one is multiplied (registers, npc <= 16 pieces per lane) and written to LDS
+    // behind it: a wave used to load, wait, multiply and store in turn (62 us for the 512 x 1024 keyframe, 2.6 TB/s).
+    f32x4 nx[NPC];
+    auto fetch = [&](long long tile) {
         const long long px0 = tile * 32;
-        for (int j = 0; j < npc; ++j) {                     // stage the tile: consecutive lanes, consecutive 16-byte pieces
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {
             const int i = lane + 64 * j, r = i / c4n, c = (i - r * c4n) * 4;
-            if (i < 32 * c4n) {
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (px0 + r < total) v = *reinterpret_cast<const f32x4 *>(p + (size_t)(px0 + r) * p_ld + c);
-                *reinterpret_cast<f32x4 *>(Pl + r * PS + c) = v;
-            }
+            nx[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < npc && i < 32 * c4n && px0 + r < total) nx[j] = *reinterpret_cast<const f32x4 *>(p + (size_t)(px0 + r) * p_ld + c);
         }
+    };
+    const long long tstep = (long long)gridDim.x * 4;
+    long long tile = (long long)blockIdx.x * 4 + (tid >> 6);
+    if (tile < ntile) fetch(tile);
+    for (; tile < ntile; tile += tstep) {
+        const long long px0 = tile * 32;
+#pragma unroll
+        for (int j = 0; j < NPC; ++j) {                     // stage the tile: consecutive lanes, consecutive 16-byte pieces
+            const int i = lane + 64 * j, r = i / c4n, c = (i - r * c4n) * 4;
+            if (j < npc && i < 32 * c4n) *reinterpret_cast<f32x4 *>(Pl + r * PS + c) = nx[j];
+        }
+        if (tile + tstep < ntile) fetch(tile + tstep);
         f32x16 acc;
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -856,10 +870,17 @@ extern "C" int arseg_head_fwd(const float *p, int p_ld, const float *wf, const f
     if (!(C & 7) && C <= 128 && ARSEG_ALIGNED16(p) && ARSEG_ALIGNED16(wf)) {           // fp32 matrix-core kernel: 4 waves x 32-pixel tiles per workgroup
         const size_t sm = (size_t)(5 * 32 * (C + 4) + 32) * sizeof(float);
         static ArsegSmemAttr attr;
-        if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(head_mfma_kernel), sm)) return e;
         const long long ntile = ((long long)N * HW + 31) / 32;
         long long gb = (ntile + 3) / 4;
-        hipLaunchKernelGGL(head_mfma_kernel, dim3((unsigned)(gb > 2048 ? 2048 : gb)), dim3(256), sm, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        const dim3 grid((unsigned)(gb > 2048 ? 2048 : gb));
+        if (C <= 64) {
+            if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(head_mfma_kernel<8>), sm)) return e;
+            hipLaunchKernelGGL(head_mfma_kernel<8>, grid, dim3(256), sm, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        } else {
+            static ArsegSmemAttr attr16;
+            if (int e = arseg_allow_smem(attr16, reinterpret_cast<const void *>(head_mfma_kernel<16>), sm)) return e;
+            hipLaunchKernelGGL(head_mfma_kernel<16>, grid, dim3(256), sm, st, p, p_ld, wf, bf, logits, N, HW, C, n_cls, log_softmax);
+        }
         return arseg_launch_status();
     }
     const size_t smem = (size_t)n_cls * C * sizeof(float);
