@@ -91,6 +91,8 @@ PROTOTYPES = {
     "arseg_maxpool3x3s2_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_fwd": (c_int, [_P, c_int, _P, c_int, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_adaptive_avgpool_blockrow_fwd": (c_int, [_P, c_int, _P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_psp_pool_matrix_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, POINTER(c_int)]),
+    "arseg_psp_pool_matrix_fwd": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_psp_prior_sum_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_global_reduce_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_resize_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),

@@ -87,6 +87,65 @@ __global__ __launch_bounds__(CV * PL) void window_reduce_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------ pyramid pooling in one pass over the map (PSPModule, model/pspnet.py:14-31)
+// The adaptive-average bins of the pyramid levels overlap within a level (H not divisible by s) and across levels, but every bin is a union of
+// cells of the grid spanned by ALL bin edges of all levels (<= 25 edges per axis).  Stage 1 sums every cell (each pixel is read exactly once: the
+// four per-level launches read the map four times, 184 MB instead of 46 MB for the 11-frame LR batch), stage 2 adds the cells of a bin, divides
+// by its pixel count and writes the block-structured row (its level's column block, zeros in the sibling blocks).
+struct PoolGrid { int ny, nx, nlev, rows; int ey[26], ex[26]; int size[4], off[4]; };
+
+__global__ __launch_bounds__(256) void psp_cells_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ cells, int H, int W, int C, PoolGrid g) {
+    __shared__ f32x4 red[16][17];
+    const int cell = blockIdx.x, cy = cell / g.nx, cx = cell - cy * g.nx, n = blockIdx.z;
+    const int y0 = g.ey[cy], y1 = g.ey[cy + 1], x0 = g.ex[cx], x1 = g.ex[cx + 1];
+    const int cv = threadIdx.x & 15, pl = threadIdx.x >> 4, c = blockIdx.y * 64 + cv * 4;
+    const int ww = x1 - x0, cnt = (y1 - y0) * ww;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int i = pl; i < cnt; i += 16) {
+            const int yy = y0 + i / ww, xx = x0 + i % ww;
+            acc += *reinterpret_cast<const f32x4 *>(in + (((size_t)n * H + yy) * W + xx) * in_ld + c);
+        }
+    red[pl][cv] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) {
+        if (pl < s) red[pl][cv] += red[pl + s][cv];
+        __syncthreads();
+    }
+    if (pl == 0 && c < C) *reinterpret_cast<f32x4 *>(cells + ((size_t)n * g.ny * g.nx + cell) * C + c) = red[0][cv];
+}
+
+__global__ __launch_bounds__(256) void psp_bins_kernel(const float *__restrict__ cells, float *__restrict__ out, int H, int W, int C, PoolGrid g) {
+    const int row = blockIdx.x, n = blockIdx.y;
+    int lev = 0;
+    while (lev + 1 < g.nlev && row >= g.off[lev + 1]) ++lev;
+    const int s = g.size[lev], b = row - g.off[lev], by = b / s, bx = b - by * s;
+    const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s, x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
+    const float inv = 1.0f / (float)((y1 - y0) * (x1 - x0));
+    const float *cn = cells + (size_t)n * g.ny * g.nx * C;
+    float *o = out + ((size_t)n * g.rows + row) * ((size_t)g.nlev * C);
+    // the cells of a bin are a rectangle of the cell grid (both are cut at the same edges): no tests inside the loops, four loads in flight
+    int cy0 = 0, cy1 = g.ny, cx0 = 0, cx1 = g.nx;
+    while (g.ey[cy0] < y0) ++cy0;
+    while (g.ey[cy1] > y1) --cy1;
+    while (g.ex[cx0] < x0) ++cx0;
+    while (g.ex[cx1] > x1) --cx1;
+    const int nc = (cy1 - cy0) * (cx1 - cx0), cw = cx1 - cx0;
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        auto cell = [&](int i) { return *reinterpret_cast<const f32x4 *>(cn + (size_t)((cy0 + i / cw) * g.nx + cx0 + i % cw) * C + c); };
+        int i = 0;
+        for (; i + 4 <= nc; i += 4) {
+            const f32x4 v0 = cell(i), v1 = cell(i + 1), v2 = cell(i + 2), v3 = cell(i + 3);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        for (; i < nc; ++i) a0 += cell(i);
+        const f32x4 acc = (a0 + a1) + (a2 + a3);
+        for (int j = 0; j < g.nlev; ++j) *reinterpret_cast<f32x4 *>(o + (size_t)j * C + c) = j == lev ? acc * inv : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 // ------------------------------------------------------------------ resize
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const float *__restrict__ in, float *__restrict__ out, int N, int C,
                                                           int Hin, int Win, int Hout, int Wout, int mode, int align, int in_ld,
@@ -780,6 +839,56 @@ extern "C" int arseg_adaptive_avgpool_blockrow_fwd(const float *in, int in_ld, f
         hipLaunchKernelGGL((window_reduce_kernel<false, 256>), grid, dim3(1024), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
     else
         hipLaunchKernelGGL((window_reduce_kernel<false, 64>), grid, dim3(256), 0, arseg_stream(stream), in, in_ld, o, out_ld, out_n_stride, H, W, C, oh, ow, n_blocks, block);
+    return arseg_launch_status();
+}
+
+static int pool_grid(int H, int W, int n_sizes, const int *sizes, PoolGrid *g) {
+    if (n_sizes < 1 || n_sizes > 4) return ARSEG_EINVAL;
+    g->nlev = n_sizes; g->rows = 0;
+    for (int i = 0; i < 4; ++i) { g->size[i] = 1; g->off[i] = 0; }
+    int ey[64], ex[64], ny = 0, nx = 0;
+    for (int i = 0; i < n_sizes; ++i) {
+        const int s = sizes[i];
+        if (s <= 0 || s > 6) return ARSEG_EUNSUPPORTED;
+        g->size[i] = s; g->off[i] = g->rows; g->rows += s * s;
+        for (int b = 0; b < s; ++b) {
+            ey[ny++] = (b * H) / s; ey[ny++] = ((b + 1) * H + s - 1) / s;
+            ex[nx++] = (b * W) / s; ex[nx++] = ((b + 1) * W + s - 1) / s;
+        }
+    }
+    auto uniq = [](int *a, int n) {
+        for (int i = 1; i < n; ++i) { const int v = a[i]; int j = i - 1; while (j >= 0 && a[j] > v) { a[j + 1] = a[j]; --j; } a[j + 1] = v; }
+        int m = 0;
+        for (int i = 0; i < n; ++i) if (m == 0 || a[m - 1] != a[i]) a[m++] = a[i];
+        return m;
+    };
+    ny = uniq(ey, ny); nx = uniq(ex, nx);
+    if (ny > 26 || nx > 26) return ARSEG_EUNSUPPORTED;
+    for (int i = 0; i < ny; ++i) g->ey[i] = ey[i];
+    for (int i = 0; i < nx; ++i) g->ex[i] = ex[i];
+    g->ny = ny - 1; g->nx = nx - 1;
+    return ARSEG_OK;
+}
+
+// The folded pyramid's pooled matrix [N][rows][n_sizes * C] (rows = sum s^2: level i's adaptive average pool in columns [i*C, (i+1)*C) of its
+// rows, zeros elsewhere) in one pass over the map; workspace = the cell sums.
+extern "C" size_t arseg_psp_pool_matrix_workspace_bytes(int N, int H, int W, int C, int n_sizes, const int *sizes) {
+    PoolGrid g;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || !sizes || pool_grid(H, W, n_sizes, sizes, &g) != ARSEG_OK) return 0;
+    return (size_t)N * g.ny * g.nx * C * sizeof(float);
+}
+
+extern "C" int arseg_psp_pool_matrix_fwd(const float *in, int in_ld, float *out, void *workspace, size_t workspace_bytes, int N, int H, int W, int C,
+                                         int n_sizes, const int *sizes, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out); ARSEG_CHECK_PTR(workspace); ARSEG_CHECK_PTR(sizes);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    if ((C & 3) || (in_ld & 3) || in_ld < C || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out) || !ARSEG_ALIGNED16(workspace) || N > 65535) return ARSEG_EINVAL;
+    PoolGrid g;
+    if (int e = pool_grid(H, W, n_sizes, sizes, &g)) return e;
+    if (workspace_bytes < (size_t)N * g.ny * g.nx * C * sizeof(float)) return ARSEG_EWORKSPACE;
+    hipStream_t hs = arseg_stream(stream);
+    hipLaunchKernelGGL(psp_cells_kernel, dim3(g.ny * g.nx, arseg_cdiv(C, 64), N), dim3(256), 0, hs, in, in_ld, reinterpret_cast<float *>(workspace), H, W, C, g);
+    hipLaunchKernelGGL(psp_bins_kernel, dim3(g.rows, N), dim3(256), 0, hs, reinterpret_cast<const float *>(workspace), out, H, W, C, g);
     return arseg_launch_status();
 }
 

@@ -1157,6 +1157,13 @@ def psp_pool_matrix(x: torch.Tensor, sizes) -> torch.Tensor:
     N, H, W, C = x.shape
     n, rows = len(sizes), sum(s * s for s in sizes)
     out = torch.empty((N, rows, 1, n * C), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    arr = (ctypes.c_int * n)(*[int(s) for s in sizes])
+    nb = lib.arseg_psp_pool_matrix_workspace_bytes(N, H, W, C, n, arr) if (n <= 4 and C % 4 == 0 and N <= 65535) else 0
+    if nb:          # one pass over the map: the cells of the grid spanned by all bin edges are summed once, then combined per bin
+        ws = torch.empty((nb // 4,), dtype=torch.float32, device=x.device)
+        _launch("adaptive_avgpool", lib.arseg_psp_pool_matrix_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), _ptr(ws), nb, N, H, W, C, n, arr, _stream())
+        return out
     off = 0
     for i, s in enumerate(sizes):
         _launch("adaptive_avgpool", _lib.load().arseg_adaptive_avgpool_blockrow_fwd, _ptr(x), _nhwc_ld(x), _ptr(out[0, off]), rows * n * C,

@@ -316,6 +316,12 @@ int arseg_adaptive_avgpool_fwd(const float *in, int in_ld, float *out, int out_l
  * rows -- no fill launch.  `out` = the level's first row in image 0 (column 0 of the matrix), out_n_stride = elements between images. */
 int arseg_adaptive_avgpool_blockrow_fwd(const float *in, int in_ld, float *out, long long out_n_stride, int N, int H, int W, int C,
                                         int oh, int ow, int n_blocks, int block, arseg_stream_t stream);
+/* The whole pooled matrix of the folded pyramid in one pass over the map: out [N][rows][n_sizes * C], rows = sum sizes[i]^2, identical to n_sizes
+ * calls of arseg_adaptive_avgpool_blockrow_fwd up to the order of summation (every bin is a union of cells of the grid spanned by all bin
+ * edges; the cells are summed once, 1 / 4 of the reads).  sizes[i] <= 6, n_sizes <= 4; workspace = arseg_psp_pool_matrix_workspace_bytes. */
+size_t arseg_psp_pool_matrix_workspace_bytes(int N, int H, int W, int C, int n_sizes, const int *sizes);
+int arseg_psp_pool_matrix_fwd(const float *in, int in_ld, float *out, void *workspace, size_t workspace_bytes, int N, int H, int W, int C,
+                              int n_sizes, const int *sizes, arseg_stream_t stream);
 /* PSPModule priors (model/pspnet.py:27-30), folded: with t[n][off_s + i][c] the per-level maps AFTER the stage conv and
  * the level's slice of the bottleneck conv (both 1x1, i.e. linear and commuting with bilinear upsampling), this writes
  * out[n,y,x,c] = sum_s upsample_bilinear(align_corners=False)(t_s[n])(y,x,c); off_s = sum_{j<s} sizes[j]^2 (host array). */

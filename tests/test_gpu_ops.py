@@ -330,6 +330,27 @@ def test_maxpool(dev, H, W, C):
     assert maxdiff(got, F.max_pool2d(x, 3, 2, 1)) == 0.0
 
 
+@pytest.mark.parametrize("N,H,W,C,sizes", [(2, 32, 64, 512, (1, 2, 3, 6)), (1, 45, 90, 128, (1, 2, 3, 6)), (2, 9, 13, 68, (1, 2, 3, 6)), (3, 7, 5, 64, (2, 5)),
+                                            (1, 4, 4, 32, (6,))])
+def test_psp_pool_matrix(dev, N, H, W, C, sizes):
+    """The folded pyramid's pooled matrix in one pass over the map (cell sums on the grid of all bin edges, then bins): every level's block equals
+    F.adaptive_avg_pool2d (overlapping bins at non-divisible sizes, bins larger than the map), the sibling blocks are exact zeros."""
+    from arseg_amd import ops
+
+    x = rnd(53, N, C, H, W)
+    got = ops.psp_pool_matrix(x.permute(0, 2, 3, 1).contiguous().to(dev), sizes).cpu()
+    n, off = len(sizes), 0
+    assert got.shape == (N, sum(s * s for s in sizes), 1, n * C)
+    for i, s in enumerate(sizes):
+        ref = F.adaptive_avg_pool2d(x, (s, s)).permute(0, 2, 3, 1).reshape(N, s * s, C)
+        blk = got[:, off:off + s * s, 0, :].reshape(N, s * s, n, C)
+        assert maxdiff(blk[:, :, i], ref) <= 1e-6
+        others = blk.clone()
+        others[:, :, i] = 0
+        assert float(others.abs().max()) == 0.0
+        off += s * s
+
+
 @pytest.mark.parametrize("H,W,C,s", [(9, 12, 512, 1), (9, 12, 512, 2), (9, 12, 512, 3), (9, 12, 512, 6), (4, 5, 64, 6), (32, 64, 68, 3)])
 def test_adaptive_avgpool_and_global_reduce(dev, H, W, C, s):
     from arseg_amd import _lib, ops
