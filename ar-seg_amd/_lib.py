@@ -95,6 +95,8 @@ PROTOTYPES = {
     "arseg_psp_pool_matrix_fwd": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_psp_prior_sum_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, POINTER(c_int), _STREAM]),
     "arseg_global_reduce_fwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
+    "arseg_global_reduce_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "arseg_global_reduce_ws_fwd": (c_int, [_P, c_int, _P, _P, c_size_t, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_resize_fwd": (c_int, [_P, _P] + [c_int] * 11 + [_STREAM]),
     "arseg_scale_add_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, _STREAM]),
     "arseg_head_fwd": (c_int, [_P, c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),

@@ -87,6 +87,51 @@ __global__ __launch_bounds__(CV * PL) void window_reduce_kernel(const float *__r
     }
 }
 
+// ------------------------------------------------------------------ global mean / max of large maps in two deterministic stages
+// One workgroup per 16 channels and image (window_reduce_kernel with a 1 x 1 output) leaves the chip idle for a single keyframe: 16 workgroups
+// read an 8 MB map (32 us in a GOP step).  Stage 1: the image is cut into `parts` row bands, a workgroup reduces one band x 64 channels into
+// the workspace [N][parts][C]; stage 2 combines the parts in order.
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void global_parts_kernel(const float *__restrict__ in, int in_ld, float *__restrict__ ws, int HW, int C, int parts) {
+    __shared__ f32x4 red[16][17];
+    const int part = blockIdx.x, n = blockIdx.z, cv = threadIdx.x & 15, pl = threadIdx.x >> 4, c = blockIdx.y * 64 + cv * 4;
+    const int per = (HW + parts - 1) / parts, p0 = part * per, p1 = min(p0 + per, HW);
+    f32x4 acc = IS_MAX ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int i = p0 + pl; i < p1; i += 16) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(in + ((size_t)n * HW + i) * in_ld + c);
+            if (IS_MAX) { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
+            else acc += v;
+        }
+    red[pl][cv] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int s = 8; s >= 1; s >>= 1) {
+        if (pl < s) {
+            const f32x4 o = red[pl + s][cv];
+            f32x4 t = red[pl][cv];
+            if (IS_MAX) { t[0] = fmaxf(t[0], o[0]); t[1] = fmaxf(t[1], o[1]); t[2] = fmaxf(t[2], o[2]); t[3] = fmaxf(t[3], o[3]); }
+            else t += o;
+            red[pl][cv] = t;
+        }
+        __syncthreads();
+    }
+    if (pl == 0 && c < C) *reinterpret_cast<f32x4 *>(ws + ((size_t)n * parts + part) * C + c) = red[0][cv];
+}
+template <bool IS_MAX>
+__global__ __launch_bounds__(256) void global_combine_kernel(const float *__restrict__ ws, float *__restrict__ out, int HW, int C, int parts) {
+    const int n = blockIdx.y, c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= C) return;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(ws + (size_t)n * parts * C + c);
+    for (int q = 1; q < parts; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ws + ((size_t)n * parts + q) * C + c);
+        if (IS_MAX) { acc[0] = fmaxf(acc[0], v[0]); acc[1] = fmaxf(acc[1], v[1]); acc[2] = fmaxf(acc[2], v[2]); acc[3] = fmaxf(acc[3], v[3]); }
+        else acc += v;
+    }
+    if (!IS_MAX) acc = acc / (float)HW;
+    *reinterpret_cast<f32x4 *>(out + (size_t)n * C + c) = acc;
+}
+
 // ------------------------------------------------------------------ pyramid pooling in one pass over the map (PSPModule, model/pspnet.py:14-31)
 // The adaptive-average bins of the pyramid levels overlap within a level (H not divisible by s) and across levels, but every bin is a union of
 // cells of the grid spanned by ALL bin edges of all levels (<= 25 edges per axis).  Stage 1 sums every cell (each pixel is read exactly once: the
@@ -928,6 +973,41 @@ extern "C" int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, i
     } else return ARSEG_EINVAL;
     return arseg_launch_status();
 }
+
+static int global_parts(int N, int H, int W, int C) {          // row bands per image of the two-stage reduce (0: the one-launch form is fine)
+    const long long HW = (long long)H * W, blocks = (long long)N * arseg_cdiv(C, 64);
+    if ((long long)N * arseg_cdiv(C, 16) >= 64 || HW < 2048 || HW >= (1ll << 31)) return 0;      // (the one-launch form already has enough workgroups)
+    long long parts = 768 / blocks;
+    if (parts > HW / 256) parts = HW / 256;
+    return parts >= 2 ? (int)parts : 0;
+}
+extern "C" size_t arseg_global_reduce_workspace_bytes(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+    return (size_t)N * global_parts(N, H, W, C) * C * sizeof(float);
+}
+// arseg_global_reduce_fwd with a workspace (arseg_global_reduce_workspace_bytes; 0 bytes = not needed): large maps of few images are reduced in
+// two deterministic stages so that the whole chip reads them.
+extern "C" int arseg_global_reduce_ws_fwd(const float *in, int in_ld, float *out, void *workspace, size_t workspace_bytes, int N, int H, int W, int C,
+                                          int op, arseg_stream_t stream) {
+    const int parts = (N > 0 && H > 0 && W > 0 && C > 0) ? global_parts(N, H, W, C) : 0;
+    if (!parts || !workspace || N > 65535) return arseg_global_reduce_fwd(in, in_ld, out, N, H, W, C, op, stream);
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out);
+    if ((C & 3) || (in_ld & 3) || in_ld < C || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out) || !ARSEG_ALIGNED16(workspace)) return ARSEG_EINVAL;
+    if (workspace_bytes < (size_t)N * parts * C * sizeof(float)) return ARSEG_EWORKSPACE;
+    if (op != ARSEG_REDUCE_MEAN && op != ARSEG_REDUCE_MAX) return ARSEG_EINVAL;
+    hipStream_t hs = arseg_stream(stream);
+    float *ws = reinterpret_cast<float *>(workspace);
+    const dim3 g1(parts, arseg_cdiv(C, 64), N), g2(arseg_cdiv(C, 1024), N);
+    if (op == ARSEG_REDUCE_MAX) {
+        hipLaunchKernelGGL(global_parts_kernel<true>, g1, dim3(256), 0, hs, in, in_ld, ws, H * W, C, parts);
+        hipLaunchKernelGGL(global_combine_kernel<true>, g2, dim3(256), 0, hs, ws, out, H * W, C, parts);
+    } else {
+        hipLaunchKernelGGL(global_parts_kernel<false>, g1, dim3(256), 0, hs, in, in_ld, ws, H * W, C, parts);
+        hipLaunchKernelGGL(global_combine_kernel<false>, g2, dim3(256), 0, hs, ws, out, H * W, C, parts);
+    }
+    return arseg_launch_status();
+}
+
 
 extern "C" int arseg_resize_fwd(const float *in, float *out, int N, int C, int Hin, int Win, int Hout, int Wout, int mode,
                                 int align_corners, int layout, int in_ld, int out_ld, arseg_stream_t stream) {

@@ -1256,7 +1256,10 @@ def global_reduce(x: torch.Tensor, op: int) -> torch.Tensor:
     _need_gpu(x)
     N, H, W, C = x.shape
     out = torch.empty((N, 1, 1, C), dtype=torch.float32, device=x.device)
-    _launch("global_reduce", _lib.load().arseg_global_reduce_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), N, H, W, C, op, _stream())
+    lib = _lib.load()
+    nb = lib.arseg_global_reduce_workspace_bytes(N, H, W, C)
+    ws = torch.empty((nb // 4,), dtype=torch.float32, device=x.device) if nb else None       # (large map, few images: two-stage reduce)
+    _launch("global_reduce", lib.arseg_global_reduce_ws_fwd, _ptr(x), _nhwc_ld(x), _ptr(out), _ptr(ws), nb, N, H, W, C, op, _stream())
     return out
 
 

@@ -330,6 +330,11 @@ int arseg_psp_prior_sum_fwd(const float *t, float *out, int N, int H, int W, int
 /* torch.mean(x,(2,3)) / F.adaptive_max_pool2d(x,1): out [N][C]   model/bisenet.py:252,292,390; pspnet.py:94 */
 int arseg_global_reduce_fwd(const float *in, int in_ld, float *out, int N, int H, int W, int C, int op,
                             arseg_stream_t stream);
+/* The same reduction with a caller-owned workspace (arseg_global_reduce_workspace_bytes, 0 = not needed): a large map of few images (the keyframe's
+ * auxiliary head) is reduced in two deterministic stages -- row bands into the workspace, then the bands in order -- so that the whole chip reads it. */
+size_t arseg_global_reduce_workspace_bytes(int N, int H, int W, int C);
+int arseg_global_reduce_ws_fwd(const float *in, int in_ld, float *out, void *workspace, size_t workspace_bytes, int N, int H, int W, int C, int op,
+                               arseg_stream_t stream);
 /* F.interpolate / F.upsample / nn.Upsample: nearest or bilinear, align_corners on/off, either layout.
  * NHWC: in_ld/out_ld channel strides (C % 4 == 0); NCHW: planes contiguous, ld arguments ignored.
  * model/pspnet.py:29,45,97; model/bisenet.py:215,284,298,442; evaluation.py:117,188,201 */

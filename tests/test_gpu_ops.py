@@ -330,6 +330,26 @@ def test_maxpool(dev, H, W, C):
     assert maxdiff(got, F.max_pool2d(x, 3, 2, 1)) == 0.0
 
 
+@pytest.mark.parametrize("N,H,W,C", [(1, 64, 128, 256), (2, 80, 70, 36), (1, 128, 256, 64), (11, 32, 64, 256)])
+def test_global_reduce_two_stage(dev, N, H, W, C):
+    """Global mean / max of large maps of few images: two deterministic stages through a workspace (row bands, then the bands in order); also a
+    channel slice of a wider buffer, all-negative channels for the max, and run-to-run bit equality."""
+    from arseg_amd import _lib, ops
+
+    x = rnd(54, N, C, H, W)
+    x[:, 0] = -x[:, 0].abs() - 1.0
+    x[:, 3, 5, 7] = 1e30
+    wide = torch.zeros(N, H, W, C + 4, device=dev)
+    wide[..., 4:] = x.permute(0, 2, 3, 1).to(dev)
+    mx = ops.global_reduce(wide[..., 4:], _lib.REDUCE_MAX).reshape(N, C)
+    assert torch.equal(mx.cpu(), x.amax(dim=(2, 3)))
+    x[:, 3, 5, 7] = 0.5
+    wide[..., 4:] = x.permute(0, 2, 3, 1).to(dev)
+    mean = ops.global_reduce(wide[..., 4:], _lib.REDUCE_MEAN).reshape(N, C)
+    assert maxdiff(mean, x.double().mean(dim=(2, 3)).float()) <= 2e-6
+    assert torch.equal(mean, ops.global_reduce(wide[..., 4:], _lib.REDUCE_MEAN).reshape(N, C))
+
+
 @pytest.mark.parametrize("N,H,W,C,sizes", [(2, 32, 64, 512, (1, 2, 3, 6)), (1, 45, 90, 128, (1, 2, 3, 6)), (2, 9, 13, 68, (1, 2, 3, 6)), (3, 7, 5, 64, (2, 5)),
                                             (1, 4, 4, 32, (6,))])
 def test_psp_pool_matrix(dev, N, H, W, C, sizes):
