@@ -769,11 +769,11 @@ unsigned long long *g_rr_dbg = nullptr;
 extern "C" void arseg__rr_set_dbg(void *ptr) { g_rr_dbg = (unsigned long long *)ptr; }
 #endif
 
-extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
-                                    const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
-                                    const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
-                                    float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
-                                    arseg_stream_t stream) {
+extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
+                                       const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
+                                       const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
+                                       float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
+                                       int impl, int seg_rows, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(ref_nhwc_host); ARSEG_CHECK_PTR(mv_q); ARSEG_CHECK_PTR(lr); ARSEG_CHECK_PTR(wq); ARSEG_CHECK_PTR(bq); ARSEG_CHECK_PTR(wk);
     ARSEG_CHECK_PTR(bk); ARSEG_CHECK_PTR(wv); ARSEG_CHECK_PTR(bv); ARSEG_CHECK_PTR(p_out);
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp); ARSEG_CHECK_POS(hp); ARSEG_CHECK_POS(wp);
@@ -792,11 +792,15 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
         if (n_cls > 32) return ARSEG_EUNSUPPORTED;
         if (!ARSEG_ALIGNED16(wf)) return ARSEG_EINVAL;
     }
-    RRParams p;
-    for (int i = 0; i < N; ++i) {
+    if (impl != ARSEG_CREFF_WARP_AUTO && impl != ARSEG_CREFF_WARP_TILES && impl != ARSEG_CREFF_WARP_ROLL) return ARSEG_EINVAL;
+    if (seg_rows < 0) return ARSEG_EINVAL;
+    for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
-        p.ref[i] = ref_nhwc_host[i];
-    }
+    if (impl == ARSEG_CREFF_WARP_ROLL)            // the rolling kernel (creff_roll.hip); not yet the default
+        return arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
+                                       log_softmax, N, Hp, Wp, hp, wp, seg_rows, arseg_stream(stream));
+    RRParams p;
+    for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
     for (int i = N; i < MAXN; ++i) p.ref[i] = nullptr;
     p.mv = mv_q; p.lr = lr; p.wq = wq; p.bq = bq; p.wk = wk; p.bk = bk; p.wv = wv; p.bv = bv; p.wf = wf; p.bf = bf;
     p.p_out = p_out; p.logits = logits;
@@ -812,4 +816,13 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
     hipStream_t st = arseg_stream(stream);
     if (!head) return launch<0>(p, st);
     return n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
+}
+
+extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
+                                    const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
+                                    const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
+                                    float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
+                                    arseg_stream_t stream) {
+    return arseg_creff_warp_fwd_ex(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits, log_softmax,
+                                   N, C, Hp, Wp, hp, wp, kH, kW, ARSEG_CREFF_WARP_AUTO, 0, stream);
 }

@@ -40,6 +40,7 @@ enum arseg_flow_dtype { ARSEG_FLOW_F32 = 0, ARSEG_FLOW_F64 = 1 };
 enum arseg_resize_mode { ARSEG_NEAREST = 0, ARSEG_BILINEAR = 1 };
 enum arseg_reduce_op { ARSEG_REDUCE_MEAN = 0, ARSEG_REDUCE_MAX = 1 };
 enum arseg_dtype { ARSEG_DT_F32 = 0, ARSEG_DT_F16 = 1, ARSEG_DT_BF16 = 2 };   /* storage element type of the 16-bit entry points */
+enum arseg_creff_warp_impl { ARSEG_CREFF_WARP_AUTO = 0, ARSEG_CREFF_WARP_TILES = 1 /* creff_rr.hip */, ARSEG_CREFF_WARP_ROLL = 2 /* creff_roll.hip */ };
 enum arseg_creff_impl { ARSEG_CREFF_AUTO = 0, ARSEG_CREFF_MFMA = 1 /* split-fp16 matrix-core kernel */, ARSEG_CREFF_VALU = 2 /* fp32 VALU kernel */ };
 
 typedef void *arseg_stream_t; /* hipStream_t */
@@ -130,6 +131,16 @@ int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q,
                          const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
                          float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
                          arseg_stream_t stream);
+
+/* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_warp_impl -- AUTO / ROLL: the rolling
+ * kernel (creff_roll.hip: a workgroup walks down a 16-column strip, key / value records of the 7 x 7 windows in LDS rings, producer and
+ * consumer waves of different rows overlap); TILES: the 16 x 16 tile kernel of rounds 2-3 (creff_rr.hip).  seg_rows = rows of a strip
+ * segment (the unit of work of the rolling kernel; 0 = default, rounded up to even).  No environment variables are read. */
+int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
+                            const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
+                            const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
+                            float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
+                            int impl, int seg_rows, arseg_stream_t stream);
 
 /* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_impl (AUTO: the matrix-core kernel
  * for C >= 128, the VALU kernel otherwise); mfma_tile_rows = 0 (by launch size), 8 or 16.  No environment variables are read. */
