@@ -137,7 +137,7 @@ __device__ __forceinline__ float rows_sum(float x) {
 __device__ __forceinline__ double uniform_f64(double x) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
     unsigned lo, hi;                                 // (asm: the builtin is sunk to the use and the VGPR pair stays live)
-    asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"((unsigned)u), "v"((unsigned)(u >> 32)));
+    asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"((unsigned)u), "v"((unsigned)(u >> 32)));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 __device__ __forceinline__ int key_rec(int b, int k0, int base0) { return base0 + 24 * b + (k0 >= 14 - 2 * b ? 8 : 0); }
@@ -796,7 +796,8 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     if (seg_rows < 0) return ARSEG_EINVAL;
     for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
-    if (impl == ARSEG_CREFF_WARP_ROLL)            // the rolling kernel (creff_roll.hip); not yet the default
+    // the rolling kernel (creff_roll.hip) is the default; its LDS plan holds the classifier records of one block of 16 classes
+    if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16)))
         return arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
                                        log_softmax, N, Hp, Wp, hp, wp, seg_rows, arseg_stream(stream));
     RRParams p;
