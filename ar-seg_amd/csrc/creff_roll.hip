@@ -32,6 +32,9 @@
 #ifndef ROLL_PNT
 #define ROLL_PNT 2            // cache policy of the p / logits stores: 2 = nontemporal
 #endif
+#ifndef ROLL_CPRIO
+#define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
+#endif
 #include "warp_math.h"
 
 namespace {
@@ -42,30 +45,31 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int CH = 64, NT = 1024, NCONS = 4, NPL = NT - 64 * NCONS;      // 768 producer lanes: one gather unit (pixel, channel group) each
+constexpr int CH = 64, NT = 1024, NCONS = 4;         // 16 waves: 4 consumers + 768 producer lanes, one gather unit (pixel, channel group) each
 constexpr int SW = 16;                               // query columns of a strip (two 8-column patches)
 constexpr int RW = SW + 6;                           // key / value record columns (22)
 constexpr int GW = SW + 8;                           // warped keyframe columns (24): + 1 for the depthwise convs
 constexpr int LW = SW + 2;                           // lr_up columns (18)
-constexpr int KSLOT = 8, VSLOT = 10;                 // ring rows: keys are dead after H1, values after H2 of the step that read them last
-constexpr int KPL = KSLOT * RW, VPL = VSLOT * RW;    // records per channel-group plane (176: a multiple of 16 -- see creff_rr.hip; 220)
+constexpr int KSLOT = 8, VSLOT = 8;                  // ring rows = the 8 rows under the windows of a row pair: key rows are written in H2 and read
+                                                     // in H1, value rows written in H1 and read in H2 -- nobody reads a ring while it is written
+constexpr int KPL = KSLOT * RW, VPL = VSLOT * RW;    // records per channel-group plane (176: a multiple of 16 -- see creff_rr.hip)
 constexpr int WPL = GW + 1, LPL = LW + 1;            // plane pitch of the two stages in f32x4 (25 * 16 B = 16 mod 128, 19 * 16 B = 48 mod 128:
                                                      // the 8 lanes of a ds_write_b128 group -- 8 channel groups of one pixel -- cover all 32 banks)
 constexpr int NGP = 2 * GW, NLP = 2 * LW;            // staged pixels per iteration: 48 warped, 36 lr_up
-constexpr int KV_LANES = 16 * RW, Q_LANE0 = 384, TAP_LANE0 = NPL - 64;      // producer lane ranges (wave aligned)
+constexpr int KV_LANES = 16 * RW;                   // key / value lanes: producer lanes 0 .. 351 (waves 4 .. 9)
 constexpr int K_OFF = 0;
 constexpr int V_OFF = K_OFF + 16 * KPL * 16;         //  45,056
-constexpr int WS_OFF = V_OFF + 16 * VPL * 16;        // 101,376  warp stage [2 rows][16 groups][WPL]
-constexpr int LS_OFF = WS_OFF + 2 * 16 * WPL * 16;   // 114,176  lr_up stage [2 rows][16 groups][LPL]
-constexpr int Q_OFF = LS_OFF + 2 * 16 * LPL * 16;    // 123,904  query records [2 patches][4 chunks][4 groups][16 queries] {4 hi | 4 lo}
-constexpr int R_OFF = Q_OFF + 2 * 16 * 16 * 16;      // 132,096  residual records lr_up(query) [2 patches][16 groups][16 queries] fp32 x 4
-constexpr int XB_OFF = R_OFF + 2 * 16 * 16 * 16;     // 140,288  partials of the kh-1 waves [2 patches][4 chunks + {m, z}][64 lanes]
-constexpr int TW_OFF = XB_OFF + 2 * 5 * 64 * 16;     // 150,528  [48] {ex, wx, ey, wy} with the tap validity folded in
-constexpr int TO_OFF = TW_OFF + NGP * 16;            // 151,296  [48] pixel index of the NW tap | dx << 30 | dy << 31 (clamped taps)
-constexpr int WD_OFF = TO_OFF + NGP * 4;             // 151,488  depthwise weights [key | value | query][16 groups][9 taps + bias]
-constexpr int WF_OFF = WD_OFF + 3 * 160 * 16;        // 159,168  classifier records [4 chunks][4 groups][16] {4 hi | 4 lo}
-constexpr int BF_OFF = WF_OFF + 4 * 4 * 16 * 16;     // 163,264  classifier bias [16]
-constexpr int SMEM_BYTES = BF_OFF + 16 * 4;          // 163,328 <= 163,840
+constexpr int WS_OFF = V_OFF + 16 * VPL * 16;        //  90,112  warp stage [2 rows][16 groups][WPL]
+constexpr int LS_OFF = WS_OFF + 2 * 16 * WPL * 16;   // 102,912  lr_up stage [2 rows][16 groups][LPL]
+constexpr int Q_OFF = LS_OFF + 2 * 16 * LPL * 16;    // 112,640  query records [2 patches][4 chunks][4 groups][16 queries] {4 hi | 4 lo}
+constexpr int R_OFF = Q_OFF + 2 * 16 * 16 * 16;      // 120,832  residual records lr_up(query) [2 patches][16 groups][16 queries] fp32 x 4
+constexpr int XB_OFF = R_OFF + 2 * 16 * 16 * 16;     // 129,024  partials of the kh-1 waves [2 patches][4 chunks + {m, z}][64 lanes]
+constexpr int TW_OFF = XB_OFF + 2 * 5 * 64 * 16;     // 139,264  [48] {ex, wx, ey, wy} with the tap validity folded in
+constexpr int TO_OFF = TW_OFF + NGP * 16;            // 140,032  [48] pixel index of the NW tap | dx << 30 | dy << 31 (clamped taps)
+constexpr int WD_OFF = TO_OFF + NGP * 4;             // 140,224  depthwise weights [key | value | query][16 groups][9 taps + bias]
+constexpr int WF_OFF = WD_OFF + 3 * 160 * 16;        // 147,904  classifier records [4 chunks][4 groups][32] {4 hi | 4 lo}
+constexpr int BF_OFF = WF_OFF + 4 * 4 * 32 * 16;     // 156,096  classifier bias [32]
+constexpr int SMEM_BYTES = BF_OFF + 32 * 4;          // 156,224 <= 163,840
 constexpr int T_FIRST = -3;                         // first iteration of a segment (MV request of gather 0); the last is S + 5
 constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -156,6 +160,12 @@ __device__ __forceinline__ void stencil2(const f32x4 *w, const f32x4 (&r0)[3], c
 #define RT_STEPS(n) nsteps_ += (n)
 #define RT_FLUSH() do { if ((tid & 63) == 0 && p.dbg) { for (int i_ = 0; i_ < 4; ++i_) atomicAdd(p.dbg + 8 * wave + i_, tacc_[i_]); \
         atomicAdd(p.dbg + 8 * wave + 4, nsteps_); } } while (0)
+#elif defined(ROLL_MARK)
+// census builds only: comment markers in the listing at the segment boundaries (tools/roll_census.py --marks)
+#define RT_DECL do { } while (0)
+#define RT(i) asm volatile("; ROLLMARK " #i)
+#define RT_STEPS(n) do { } while (0)
+#define RT_FLUSH() do { } while (0)
 #else
 #define RT_DECL do { } while (0)
 #define RT(i) do { } while (0)
@@ -291,17 +301,26 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                 f32x4 Sc[NBK];
 #pragma unroll
                 for (int j = 0; j < NBK; ++j) Sc[j] = maskv[j];
+                // operands one chunk ahead of the MFMAs that use them (left alone, hipcc requests a key record right in front of its two
+                // MFMAs: one LDS round trip per block and chunk on the critical path of the wave)
+                u32x4 qv[4], ka[2][NBK];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qv[c] = sm.Qr[((pc * 4 + c) * 4 + g) * 16 + q];
+#pragma unroll
+                for (int j = 0; j < NBK; ++j) ka[0][j] = sm.Kr[g * KPL + krec[j]];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const u32x4 qv = sm.Qr[((pc * 4 + c) * 4 + g) * 16 + q];
-                    const u32x4 *ka = sm.Kr + (4 * c + g) * KPL;
-                    const h16x8 b1 = __builtin_bit_cast(h16x8, qv), b2 = __builtin_bit_cast(h16x8, u32x4{qv.z, qv.w, qv.x, qv.y});
+                    if (c < 3) {
 #pragma unroll
-                    for (int j = 0; j < NBK; ++j) {
-                        const h16x8 a = __builtin_bit_cast(h16x8, ka[krec[j]]);
-                        Sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b1, Sc[j], 0, 0, 0);
-                        Sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b2, Sc[j], 0, 0, 0);
+                        for (int j = 0; j < NBK; ++j) ka[(c + 1) & 1][j] = sm.Kr[(4 * (c + 1) + g) * KPL + krec[j]];
                     }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const h16x8 b1 = __builtin_bit_cast(h16x8, qv[c]), b2 = __builtin_bit_cast(h16x8, u32x4{qv[c].z, qv[c].w, qv[c].x, qv[c].y});
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) Sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ka[c & 1][j]), b1, Sc[j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) Sc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, ka[c & 1][j]), b2, Sc[j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 float m = -INFINITY;
 #pragma unroll
@@ -328,25 +347,34 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
             // ---------------------------------------------------------------- H2: P.V over this half's blocks (un-normalised)
             if (s >= 0 && s < S) {
                 // byte offset of the value record of (block b, this lane's key) in a channel-group plane
-                const int b2s = 2 * s, b10 = b2s - 10 * (b2s / 10);
+                const int b8 = (2 * s) & 7;
                 unsigned vrec[NBK];
 #pragma unroll
-                for (int j = 0; j < NBK; ++j) {
-                    const unsigned r0 = (unsigned)(vky[j] + b10);
-                    vrec[j] = (min(r0, r0 - 10u) * RW + (unsigned)vkx[j]) * 16u;
+                for (int j = 0; j < NBK; ++j) vrec[j] = (unsigned)((((vky[j] + b8) & 7) * RW + vkx[j]) * 16);
+                // value operands one chunk ahead, as the key records above
+                u32x2 vh[2][NBK], vl[2][NBK];
+                {
+                    const unsigned char *va = reinterpret_cast<const unsigned char *>(sm.Vr + (q & 3) * VPL);
+#pragma unroll
+                    for (int j = 0; j < NBK; ++j) { vh[0][j] = lds_tr16(va + vrec[j]); vl[0][j] = lds_tr16(va + vrec[j] + 8); }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const unsigned char *va = reinterpret_cast<const unsigned char *>(sm.Vr + (4 * c + (q & 3)) * VPL);
+                    if (c < 3) {
+                        const unsigned char *va = reinterpret_cast<const unsigned char *>(sm.Vr + (4 * (c + 1) + (q & 3)) * VPL);
+#pragma unroll
+                        for (int j = 0; j < NBK; ++j) { vh[(c + 1) & 1][j] = lds_tr16(va + vrec[j]); vl[(c + 1) & 1][j] = lds_tr16(va + vrec[j] + 8); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < NBK; ++j) {
-                        const u32x2 vh = lds_tr16(va + vrec[j]), vl = lds_tr16(va + vrec[j] + 8);
                         const h16x8 pb = __builtin_bit_cast(h16x8, P[j]);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh, vl), pb, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl, vh), pb, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh[c & 1][j], vl[c & 1][j]), pb, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl[c & 1][j], vh[c & 1][j]), pb, acc, 0, 0, 0);
                     }
                     Oh[c] = acc;
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 if (KH == 1) {
                     f32x4 *xb = sm.Xb + pc * 5 * 64 + lane;
@@ -366,9 +394,9 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
 // ============================================================================================== producers (waves 4..15)
 // Every producer lane owns one gather unit (staged warp pixel, channel group) and -- lanes 0..575 -- one lr_up unit; on top of that
 // a wave has ONE role (a template parameter: the roles' registers never coexist):
-//   ROLE_KV  (waves 4..9)   lane = (channel group, record column): key + value depthwise convs, records into the rings
-//   ROLE_Q   (waves 10..13) lane = (channel group, query column): query depthwise conv, query + residual records
-//   ROLE_AUX (waves 14, 15) wave 15: sampling taps of the gather two iterations ahead (one lane per staged pixel)
+//   ROLE_KV  (waves 4..9)           lane = (channel group, record column): key + value depthwise convs, records into the rings
+//   ROLE_Q   (waves 10, 11, 14, 15) lane = (channel group, query column): query depthwise conv, query + residual records
+//   ROLE_AUX (waves 12, 13)         wave 13: sampling taps of the gather two iterations ahead (one lane per staged pixel)
 // Gather pipeline (j = index of a pair of warp rows):  MVs of j requested in H2(j-3)  ->  fp64 grid arithmetic in H1(j-2)  ->  tap table in
 // H2(j-2)  ->  the four taps requested in H1(j-1), in flight for a whole iteration (the first touch of a keyframe row comes from HBM)  ->
 // blended and staged in H1(j)  ->  consumed by the convs in H2(j).
@@ -379,13 +407,15 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
     const int pl = tid - 64 * NCONS;                   // 0 .. 767
     const int gpx = pl >> 4, gcg = pl & 15;            // gather unit: staged warp pixel (row gpx / 24, column gpx % 24), channel group
     const int grr = gpx >= GW ? 1 : 0, gcc = gpx - GW * grr;
-    const bool l_lane = gpx < NLP;                     // lr_up unit: staged lr_up pixel (row gpx / 18, column gpx % 18), channel group
-    const int lrr = gpx >= LW ? 1 : 0, lcc = gpx - LW * lrr;
+    // lr_up units (staged lr_up pixel, channel group): 576 of them -- two on every lane of the four query waves (units ql, ql + 256), one
+    // on every lane of wave 12 (512 + lane); the channel group of a unit is the lane's gather channel group (all offsets are multiples of 16)
+    constexpr int NLU = ROLE == ROLE_Q ? 2 : ROLE == ROLE_AUX ? 1 : 0;
     const bool kv_ok = pl < KV_LANES;                  // key / value lane: (channel group, record column), column fastest
     const int kcg = min(pl / RW, 15), kx = pl - RW * (pl / RW);
-    const int ql = pl - Q_LANE0, qcg = (ql >> 4) & 15, qx = ql & 15;      // query lane: (channel group, query column)
-    const int tl = pl - TAP_LANE0;                     // tap lane: the last producer wave's lanes 0 .. 47, one per staged warp pixel
-    const bool tap_lane = ROLE == ROLE_AUX && tl >= 0 && tl < NGP;
+    // query lane: (channel group, query column); the four query waves are 10, 11, 14, 15 (see the role table in the kernel)
+    const int ql = ((wave < 12 ? wave - 10 : wave - 12) & 3) * 64 + (tid & 63), qcg = (ql >> 4) & 15, qx = ql & 15;
+    const int tl = tid & 63;                           // tap lane: wave 13's lanes 0 .. 47, one per staged warp pixel
+    const bool tap_lane = ROLE == ROLE_AUX && wave == 13 && tl < NGP;
     const int trr = tl >= GW ? 1 : 0, tcc = tl - GW * trr;
     const bool mv_ident = Hp == p.H && Wp == p.W;
     double g_dW = 0.0, g_dH = 0.0, g_rW = 0.0, g_rH = 0.0;
@@ -404,67 +434,92 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ref[n]), 0, (int)p.ref_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr), 0, (int)p.lr_bytes, 0x00020000);
         const unsigned lr_img = (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + 16u * gcg;
-        // lr_up column taps of this lane: the same for every row of the strip
-        unsigned lx0, lx1;
-        float lwx0, lwx1;
-        {
-            const int gx = x0 - 1 + lcc;
+        // lr_up column taps of this lane's units: the same for every row of the strip
+        bool l_lane[NLU > 0 ? NLU : 1];
+        int lrr[NLU > 0 ? NLU : 1], lcc[NLU > 0 ? NLU : 1];
+        unsigned lx0[NLU > 0 ? NLU : 1], lx1[NLU > 0 ? NLU : 1];
+        float lwx0[NLU > 0 ? NLU : 1], lwx1[NLU > 0 ? NLU : 1];
+#pragma unroll
+        for (int i = 0; i < NLU; ++i) {
+            const int px = (ROLE == ROLE_Q ? ql + 256 * i : 512 + (tid & 63)) >> 4;
+            l_lane[i] = px < NLP && (ROLE == ROLE_Q || wave == 12);
+            lrr[i] = px >= LW ? 1 : 0; lcc[i] = px - LW * lrr[i];
+            const int gx = x0 - 1 + lcc[i];
             int j0, j1; float m;
             arseg_src_index(p.sx, min(max(gx, 0), Wp - 1), true, p.wp, j0, j1, m);
             m = fminf(fmaxf(m, 0.f), 1.f);
             const float inx = (unsigned)gx < (unsigned)Wp ? 1.f : 0.f;
-            lwx0 = (1.f - m) * inx; lwx1 = m * inx;
-            lx0 = (unsigned)j0 * (CH * 4u); lx1 = (unsigned)j1 * (CH * 4u);
+            lwx0[i] = (1.f - m) * inx; lwx1[i] = m * inx;
+            lx0[i] = (unsigned)j0 * (CH * 4u); lx1[i] = (unsigned)j1 * (CH * 4u);
         }
-        f32x4 win[2][3], gv[4], gw = {0.f, 0.f, 0.f, 0.f}, savA = {0.f, 0.f, 0.f, 0.f};
-        unsigned mvv = 0u;
+        // ROLE_KV: the four warp rows under the two record rows being produced (rows 0, 1: the window; 2, 3: staged this iteration);
+        // ROLE_Q: rows 0, 1 = the window of lr_up rows
+        f32x4 row[ROLE == ROLE_KV ? 4 : 2][3], gw = {0.f, 0.f, 0.f, 0.f}, savA = {0.f, 0.f, 0.f, 0.f};
+        unsigned mvv = 0u, go = 0u, pft[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         float ngx = 0.f, ngy = 0.f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < (ROLE == ROLE_KV ? 4 : 2); ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) win[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) gv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 3; ++j) row[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
         for (int t = T_FIRST; t <= S + 5; ++t) {
             // ================================================================ H1
-            // ---- lr_up rows ys + 2t - 7, ys + 2t - 6 (+1 halo column each side): request the bilinear taps first
-            const bool l_on = t >= 3 && t <= S + 3;
-            const bool l_do = l_on && l_lane;
-            f32x4 lv[4];
-            float lwy0, lwy1;
+            // ---- gather t: the four taps of this lane's pixel (tap offsets read in H1(t-1); the lines were touched by the tap wave in H2(t-2),
+            // so these come from the L2: no load of a compute wave is in flight across a barrier -- hipcc's s_waitcnt bookkeeping otherwise
+            // makes the LDS reads of H2 wait for them)
+            f32x4 gv[4];
+#ifdef ROLL_NOGATHER
+            const bool g_on = false;
+#else
+            const bool g_on = t >= 0 && t <= S + 3;
+#endif
             {
-                const int gy = ys + 2 * t - 7 + lrr;
+                const unsigned a = g_on ? (go & 0x3FFFFFFFu) * (CH * 4u) + 16u * gcg : OOB;
+                const unsigned dxo = (go & 0x40000000u) ? CH * 4u : 0u, dyo = (go & 0x80000000u) ? (unsigned)Wp * (CH * 4u) : 0u;
+                gv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a, 0, 0));
+                gv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dxo : OOB, 0, 0));
+                gv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dyo : OOB, 0, 0));
+                gv[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dyo + dxo : OOB, 0, 0));
+            }
+            // ---- lr_up rows ys + 2t - 7, ys + 2t - 6 (+1 halo column each side): the bilinear taps (lines touched by wave 12 in H2(t-2))
+            const bool l_on = t >= 3 && t <= S + 3;
+            f32x4 lv[NLU > 0 ? NLU : 1][4];
+            float lwy0[NLU > 0 ? NLU : 1], lwy1[NLU > 0 ? NLU : 1];
+#pragma unroll
+            for (int i = 0; i < NLU; ++i) {
+#ifdef ROLL_NOLR
+                const bool l_do = false;
+#else
+                const bool l_do = l_on && l_lane[i];
+#endif
+                const int gy = ys + 2 * t - 7 + lrr[i];
                 int i0, i1; float l;
                 arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, i0, i1, l);
                 l = fminf(fmaxf(l, 0.f), 1.f);
                 const float iny = (unsigned)gy < (unsigned)Hp ? 1.f : 0.f;
-                lwy0 = (1.f - l) * iny; lwy1 = l * iny;
+                lwy0[i] = (1.f - l) * iny; lwy1[i] = l * iny;
                 const unsigned r0 = lr_img + (unsigned)(i0 * p.wp) * (CH * 4u), r1 = lr_img + (unsigned)(i1 * p.wp) * (CH * 4u);
-                lv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx0 : OOB, 0, 0));
-                lv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx1 : OOB, 0, 0));
-                lv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx0 : OOB, 0, 0));
-                lv[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx1 : OOB, 0, 0));
+                lv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx0[i] : OOB, 0, 0));
+                lv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx1[i] : OOB, 0, 0));
+                lv[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx0[i] : OOB, 0, 0));
+                lv[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx1[i] : OOB, 0, 0));
             }
-            // ---- gather t: blend the four taps requested in H1(t-1), stage
-            if (t >= 0 && t <= S + 3) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-                acc += gv[0] * (gw[0] * gw[2]);      // same order as warp_mvq_nhwc_kernel
-                acc += gv[1] * (gw[1] * gw[2]);
-                acc += gv[2] * (gw[0] * gw[3]);
-                acc += gv[3] * (gw[1] * gw[3]);
-                sm.Ws[(grr * 16 + gcg) * WPL + gcc] = acc;
-            }
-            // ---- requests of gather t + 1 (tap table of H2(t-1)); in flight until H1(t+1)
-            if (t >= -1 && t <= S + 2) {
-                const unsigned o = sm.TapO[gpx];
-                gw = sm.TapW[gpx];
-                const unsigned a = (o & 0x3FFFFFFFu) * (CH * 4u) + 16u * gcg;
-                const unsigned dxo = (o & 0x40000000u) ? CH * 4u : 0u, dyo = (o & 0x80000000u) ? (unsigned)Wp * (CH * 4u) : 0u;
-                gv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a, 0, 0));
-                gv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a + dxo, 0, 0));
-                gv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a + dyo, 0, 0));
-                gv[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a + dyo + dxo, 0, 0));
+            if (ROLE == ROLE_KV) {
+                // ---- value records of rows rho = 2k, 2k + 1 (k = t - 2) from the four warp rows the key conv of H2(t-1) used; then the window moves on
+                if (kv_ok && t >= 1 && t <= S + 4) {
+                    if (t >= 2) {
+                        const int k = t - 2, r0 = ys - 3 + 2 * k;
+                        const bool col_in = (unsigned)(x0 - 3 + kx) < (unsigned)Wp;
+                        const bool in_a = col_in && (unsigned)r0 < (unsigned)Hp, in_b = col_in && (unsigned)(r0 + 1) < (unsigned)Hp;
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 a, b;
+                        stencil2(sm.Wd + 160 + kcg * 10, row[0], row[1], row[2], row[3], a, b);
+                        sm.Vr[kcg * VPL + ((2 * k) & 7) * RW + kx] = split4r(in_a ? a : zero);
+                        sm.Vr[kcg * VPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(in_b ? b : zero);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { row[0][j] = row[2][j]; row[1][j] = row[3][j]; }
+                }
             }
             // ---- sampling position of gather t + 2 (warp rows ys - 4 + 2(t+2), +1), fp64 like the reference; the MV was requested in H2(t-1)
             if (ROLE == ROLE_AUX && tap_lane && t >= -2 && t <= S + 1) {
@@ -478,57 +533,61 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                 norm_grid_rcp(gx, gy, fx, fy, g_dW, g_dH, g_rW, g_rH, ngx, ngy);
             }
             // ---- lr_up: interpolate, stage
-            if (l_do) sm.Ls[(lrr * 16 + gcg) * LPL + lcc] = lwy0 * (lwx0 * lv[0] + lwx1 * lv[1]) + lwy1 * (lwx0 * lv[2] + lwx1 * lv[3]);
+#pragma unroll
+            for (int i = 0; i < NLU; ++i)
+                if (l_on && l_lane[i])
+                    sm.Ls[(lrr[i] * 16 + gcg) * LPL + lcc[i]] = lwy0[i] * (lwx0[i] * lv[i][0] + lwx1[i] * lv[i][1]) + lwy1[i] * (lwx0[i] * lv[i][2] + lwx1[i] * lv[i][3]);
+            // ---- gather t: blend, stage; then the tap offsets / weights of gather t + 1 (table of H2(t-1))
+            if (g_on) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                acc += gv[0] * (gw[0] * gw[2]);      // same order as warp_mvq_nhwc_kernel
+                acc += gv[1] * (gw[1] * gw[2]);
+                acc += gv[2] * (gw[0] * gw[3]);
+                acc += gv[3] * (gw[1] * gw[3]);
+                sm.Ws[(grr * 16 + gcg) * WPL + gcc] = acc;
+            }
+            if (t >= -1 && t <= S + 2) { go = sm.TapO[gpx]; gw = sm.TapW[gpx]; }
             RT(0);
             wg_sync();
             RT(1);
             // ================================================================ H2
             if (ROLE == ROLE_KV) {
-                // ---- key + value records of rows rho = 2k, 2k + 1 (k = t - 1; image rows ys - 3 + rho)
+                // ---- key records of rows rho = 2k, 2k + 1 (k = t - 1; image rows ys - 3 + rho); the value records follow in H1(t+1)
                 if (kv_ok && t >= 0 && t <= S + 3) {
-                    const f32x4 *wK = sm.Wd + kcg * 10, *wV = sm.Wd + 160 + kcg * 10;
-                    f32x4 n0[3], n1[3];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { n0[j] = sm.Ws[kcg * WPL + kx + j]; n1[j] = sm.Ws[(16 + kcg) * WPL + kx + j]; }
+                    for (int j = 0; j < 3; ++j) { row[2][j] = sm.Ws[kcg * WPL + kx + j]; row[3][j] = sm.Ws[(16 + kcg) * WPL + kx + j]; }
                     if (t >= 1) {
                         const int k = t - 1, r0 = ys - 3 + 2 * k;
                         const bool col_in = (unsigned)(x0 - 3 + kx) < (unsigned)Wp;
                         // the unfold's zero padding: records outside the image are zero
                         const bool in_a = col_in && (unsigned)r0 < (unsigned)Hp, in_b = col_in && (unsigned)(r0 + 1) < (unsigned)Hp;
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        const int ks = (2 * k) & 7, vs = 2 * k - 10 * ((2 * k) / 10);
                         f32x4 a, b;
-                        stencil2(wK, win[0], win[1], n0, n1, a, b);
-                        sm.Kr[kcg * KPL + ks * RW + kx] = split4r(in_a ? a : zero);
-                        sm.Kr[kcg * KPL + (ks + 1) * RW + kx] = split4r(in_b ? b : zero);
-                        stencil2(wV, win[0], win[1], n0, n1, a, b);
-                        sm.Vr[kcg * VPL + vs * RW + kx] = split4r(in_a ? a : zero);
-                        sm.Vr[kcg * VPL + (vs + 1) * RW + kx] = split4r(in_b ? b : zero);
+                        stencil2(sm.Wd + kcg * 10, row[0], row[1], row[2], row[3], a, b);
+                        sm.Kr[kcg * KPL + ((2 * k) & 7) * RW + kx] = split4r(in_a ? a : zero);
+                        sm.Kr[kcg * KPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(in_b ? b : zero);
                     }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { win[0][j] = n0[j]; win[1][j] = n1[j]; }
                 }
             } else if (ROLE == ROLE_Q) {
                 // ---- residual records of step t - 5: lr_up at the query pixels (row A saved in H2(t-1), row B still in the window)
                 if (t >= 5 && t <= S + 4) {
                     f32x4 *dst = sm.Rr + ((qx >> 3) * 16 + qcg) * 16 + (qx & 7);
-                    dst[0] = savA; dst[8] = win[0][1];
+                    dst[0] = savA; dst[8] = row[0][1];
                 }
                 // ---- query records of step s = t - 4 (query rows ys + 2s, + 1)
                 if (l_on) {
-                    const f32x4 *wQ = sm.Wd + 320 + qcg * 10;
                     f32x4 m0[3], m1[3];
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { m0[j] = sm.Ls[qcg * LPL + qx + j]; m1[j] = sm.Ls[(16 + qcg) * LPL + qx + j]; }
                     if (t >= 4) {
                         f32x4 a, b;
-                        stencil2(wQ, win[0], win[1], m0, m1, a, b);
+                        stencil2(sm.Wd + 320 + qcg * 10, row[0], row[1], m0, m1, a, b);
                         u32x4 *dst = sm.Qr + (((qx >> 3) * 4 + (qcg >> 2)) * 4 + (qcg & 3)) * 16 + (qx & 7);
                         dst[0] = split4r(a); dst[8] = split4r(b);
-                        savA = win[1][1];
+                        savA = row[1][1];
                     }
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) { win[0][j] = m0[j]; win[1][j] = m1[j]; }
+                    for (int j = 0; j < 3; ++j) { row[0][j] = m0[j]; row[1][j] = m1[j]; }
                 }
             } else {
                 // ---- tap table of gather t + 2 from the sampling positions of H1(t)
@@ -544,6 +603,13 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                         w = f32x4{tp.vx0 ? tp.ex : 0.f, tp.vx1 ? tp.wx : 0.f, tp.vy0 ? tp.ey : 0.f, tp.vy1 ? tp.wy : 0.f};
                     }
                     sm.TapW[tl] = w; sm.TapO[tl] = o;
+                    // touch the eight 128-byte lines of the four tap pixels: the gather lanes read them one and a half iterations from now
+                    asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]), "v"(pft[4]), "v"(pft[5]), "v"(pft[6]), "v"(pft[7]));
+                    const unsigned a = (o & 0x3FFFFFFFu) * (CH * 4u);
+                    const unsigned dxo = (o & 0x40000000u) ? CH * 4u : 0u, dyo = (o & 0x80000000u) ? (unsigned)Wp * (CH * 4u) : 0u;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        pft[i] = __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, a + ((i & 1) ? 128u : 0u) + ((i & 2) ? dxo : 0u) + ((i & 4) ? dyo : 0u), 0, 0);
                 }
                 // ---- motion vectors of gather t + 3 (identity-resize case: one int16 pair per pixel)
                 if (tap_lane && mv_ident && t <= S) {
@@ -551,6 +617,21 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     mvv = 0u;
                     if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp)
                         mvv = *reinterpret_cast<const unsigned *>(p.mv + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * 2);
+                }
+                // ---- wave 12 touches the lr pixels under the lr_up rows of iteration t + 2 (rows ys + 2t - 3, ys + 2t - 2): lane = (lr row 0..3 from
+                // the first tap row, lr column 0..15 from the first tap column of the strip), both lines of the pixel
+                if (wave == 12 && t >= 1 && t <= S + 1) {
+                    asm volatile("" :: "v"(pft[0]), "v"(pft[1]));
+                    const int tq = tid & 63;
+                    int i0, i1, ie0, ie1, j0, j1, je0, je1; float l;
+                    arseg_src_index(p.sy, min(max(ys + 2 * t - 3, 0), Hp - 1), true, p.hp, i0, i1, l);
+                    arseg_src_index(p.sy, min(max(ys + 2 * t - 2, 0), Hp - 1), true, p.hp, ie0, ie1, l);
+                    arseg_src_index(p.sx, min(max(x0 - 1, 0), Wp - 1), true, p.wp, j0, j1, l);
+                    arseg_src_index(p.sx, min(max(x0 + SW, 0), Wp - 1), true, p.wp, je0, je1, l);
+                    const int r = i0 + (tq >> 4), c = j0 + (tq & 15);
+                    const unsigned off = r <= ie1 && c <= je1 ? (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + (unsigned)(r * p.wp + c) * (CH * 4u) : OOB;
+                    pft[0] = __builtin_amdgcn_raw_buffer_load_b32(lr_rsrc, off, 0, 0);
+                    pft[1] = __builtin_amdgcn_raw_buffer_load_b32(lr_rsrc, off == OOB ? OOB : off + 128u, 0, 0);
                 }
             }
             RT(2);
@@ -561,7 +642,7 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
     RT_FLUSH();
 }
 
-template <int NB>      // NB: 1 = classifier head (<= 16 classes), 0 = no head
+template <int NB>      // NB: classifier row blocks of 16 classes (0: no head)
 __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     constexpr int NBA = NB > 0 ? NB : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -573,7 +654,6 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     sm.TapO = reinterpret_cast<unsigned *>(smem + TO_OFF); sm.Wd = reinterpret_cast<f32x4 *>(smem + WD_OFF);
     sm.Wfs = reinterpret_cast<f32x4 *>(smem + WF_OFF);        // [4 chunks][4 groups][NBA*16]
     sm.Bfs = reinterpret_cast<float *>(smem + BF_OFF);
-    static_assert(NB <= 1, "LDS holds classifier records of 16 classes");
 
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -607,14 +687,18 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     sc.u_last = (int)((long long)nunits * (xcd + 1) / nx);
 
     if (wave < NCONS) {
+        __builtin_amdgcn_s_setprio(ROLL_CPRIO);       // the consumers are the critical path of both halves of an iteration
         if (wave < 2) consumer<NB, 0>(p, sm, sc, tid, wave);
         else consumer<NB, 1>(p, sm, sc, tid, wave);
-    } else if (wave < NCONS + 6) {
+    } else if (wave < 10) {
+        // Roles by SIMD (a workgroup's waves go to the four SIMDs cyclically, so waves w and w + 4 share one): every SIMD hosts one
+        // consumer and about the same producer VALU work --  SIMD a: 0 C | 4 KV | 8 KV | 12 AUX     SIMD b: 1 C | 5 KV | 9 KV | 13 AUX (taps)
+        //                                                 SIMD c: 2 C | 6 KV | 10 Q | 14 Q       SIMD d: 3 C | 7 KV | 11 Q | 15 Q
         producer<ROLE_KV>(p, sm, sc, tid, wave);
-    } else if (wave < NCONS + 10) {
-        producer<ROLE_Q>(p, sm, sc, tid, wave);
-    } else {
+    } else if (wave == 12 || wave == 13) {
         producer<ROLE_AUX>(p, sm, sc, tid, wave);
+    } else {
+        producer<ROLE_Q>(p, sm, sc, tid, wave);
     }
 }
 
@@ -665,5 +749,5 @@ int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv
     p.dbg = g_roll_dbg;
 #endif
     if (!head) return launch<0>(p, st);
-    return n_cls <= 16 ? launch<1>(p, st) : ARSEG_EUNSUPPORTED;
+    return n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
 }

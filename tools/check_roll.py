@@ -52,7 +52,7 @@ def main():
         return s.elapsed_time(e) / iters
 
     # (Hp, Wp, hp, wp, B, mv_div (MV map = feature * mv_div), n_cls, layout)
-    cases = [(12, 16, 6, 8, 1, 1, 12, _lib.C8), (10, 12, 5, 6, 2, 1, 12, _lib.NHWC), (7, 9, 3, 4, 1, 1, 16, _lib.C8),
+    cases = [(12, 16, 6, 8, 1, 1, 12, _lib.C8), (10, 12, 5, 6, 2, 1, 12, _lib.NHWC), (7, 9, 3, 4, 1, 1, 19, _lib.C8),
              (32, 48, 16, 24, 2, 1, 12, _lib.NHWC), (33, 50, 16, 24, 1, 1, 0, _lib.C8), (64, 96, 32, 48, 3, 2, 12, _lib.NHWC),
              (140, 40, 70, 20, 2, 1, 12, _lib.C8), (300, 64, 150, 32, 1, 1, 12, _lib.NHWC)]
     if args.only_big:
