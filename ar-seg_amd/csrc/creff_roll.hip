@@ -52,7 +52,10 @@ constexpr int GW = SW + 8;                           // warped keyframe columns 
 constexpr int LW = SW + 2;                           // lr_up columns (18)
 constexpr int KSLOT = 8, VSLOT = 8;                  // ring rows = the 8 rows under the windows of a row pair: key rows are written in H2 and read
                                                      // in H1, value rows written in H1 and read in H2 -- nobody reads a ring while it is written
-constexpr int KPL = KSLOT * RW, VPL = VSLOT * RW;    // records per channel-group plane (176: a multiple of 16 -- see creff_rr.hip)
+constexpr int KPL = KSLOT * RW;                      // key records per channel-group plane: 176, a multiple of 16 (ds_read_b128 of one key
+                                                     // block: the 4 groups g land in one 256-byte bank row side by side -- see creff_rr.hip)
+constexpr int VPL = VSLOT * RW + 4;                  // value records per plane: 180 = 4 mod 16 -- the transpose read takes 8 bytes of 8 keys from
+                                                     // each of 4 planes at once: planes 64 bytes (16 banks) apart, not on top of each other
 constexpr int WPL = GW + 1, LPL = LW + 1;            // plane pitch of the two stages in f32x4 (25 * 16 B = 16 mod 128, 19 * 16 B = 48 mod 128:
                                                      // the 8 lanes of a ds_write_b128 group -- 8 channel groups of one pixel -- cover all 32 banks)
 constexpr int NGP = 2 * GW, NLP = 2 * LW;            // staged pixels per iteration: 48 warped, 36 lr_up
@@ -208,6 +211,11 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
             }
         }
     }
+    f32x4 bias[NBA];                             // classifier bias of this lane's classes 16nb + 4g .. + 3 (-inf beyond n_cls: such a class
+#pragma unroll                                   // drops out of the log-softmax by itself)
+    for (int nb = 0; nb < NBA; ++nb) bias[nb] = KH == 0 && NB > 0 ? *reinterpret_cast<const f32x4 *>(sm.Bfs + nb * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
     RT_DECL;
     for (int unit = sc.u_first; unit < sc.u_last; unit += sc.u_step) {
         const int n = unit / sc.per_img, rem = unit - n * sc.per_img;
@@ -215,22 +223,37 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
         const int x0 = strip * SW, ys = seg * p.seg_rows;
         const int S = (min(p.seg_rows, Hp - ys) + 1) >> 1;
         RT_STEPS(S);
+        // Store offsets of this lane's query pixel, split into a per-lane part that is constant down the strip (voffset; OOB for lanes
+        // whose column or class lies outside) and a wave-uniform part that moves with the step (soffset: scalar arithmetic only).
+        const int qy = q >> 3, gxq = x0 + 8 * pc + (q & 7);
+        const bool col_ok = gxq < Wp, c8 = p.p_layout == ARSEG_C8;
+        const unsigned plane = (unsigned)(Hp * Wp);
+        const unsigned vp = !col_ok ? OOB : c8 ? ((unsigned)(g >> 1) * plane + (unsigned)(qy * Wp + gxq)) * 32u + (unsigned)(g & 1) * 16u
+                                               : (unsigned)(qy * Wp + gxq) * (CH * 4u) + 16u * g;
+        const unsigned p_cstep = c8 ? 2u * plane * 32u : 64u;                                    // chunk c: + c * p_cstep
+        const unsigned p_unit = c8 ? ((unsigned)n * 8u * plane + (unsigned)(ys * Wp)) * 32u : ((unsigned)n * plane + (unsigned)(ys * Wp)) * (CH * 4u);
+        const unsigned p_rstep = (unsigned)(2 * Wp) * (c8 ? 32u : CH * 4u);                     // step s: + s * p_rstep
+        unsigned vl[NBA][4];
+#pragma unroll
+        for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cls = nb * 16 + 4 * g + i;
+                vl[nb][i] = col_ok && cls < p.n_cls ? ((unsigned)cls * plane + (unsigned)(qy * Wp + gxq)) * 4u : OOB;
+            }
+        const unsigned l_unit = ((unsigned)n * (unsigned)p.n_cls * plane + (unsigned)(ys * Wp)) * 4u, l_rstep = (unsigned)(2 * Wp) * 4u;
         f32x4 Oh[4];                                 // this half's un-normalised P.V (KH 0: carried to the merge in the next H1)
         float mh = 0.f, zh = 1.f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) Oh[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int t = T_FIRST; t <= S + 5; ++t) {
             const int s = t - 5;
-            u32x4 P[NBK];
+            u32x4 P[NBK], P2[NBK];
             // ---------------------------------------------------------------- H1 (KH 0 first): merge the halves of step s - 1, residual, classifier, stores
             if (KH == 0 && s >= 1) {
-                const int gyq = ys + 2 * (s - 1) + (q >> 3), gxq = x0 + 8 * pc + (q & 7);       // this lane's query pixel
-                const bool inq = gyq < Hp && gxq < Wp;
-                const unsigned pix = (unsigned)(gyq * Wp + gxq), plane = (unsigned)(Hp * Wp);
-                const unsigned p_off0 = p.p_layout == ARSEG_C8 ? (((unsigned)n * 8u + (unsigned)(g >> 1)) * plane + pix) * 32u + (unsigned)(g & 1) * 16u
-                                                               : ((unsigned)n * plane + pix) * (CH * 4u) + 16u * g;
-                const unsigned p_step = p.p_layout == ARSEG_C8 ? 2u * plane * 32u : 64u;      // chunk c: + c * p_step
-                const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
+                // rows of the step: ys + 2(s-1), + 1; the second one may lie below the image (odd height): those lanes store nothing
+                const bool rowok = qy == 0 || ys + 2 * (s - 1) + 1 < Hp;
+                const unsigned p_s = p_unit + (unsigned)(s - 1) * p_rstep, l_s = l_unit + (unsigned)(s - 1) * l_rstep;
                 const f32x4 *xb = sm.Xb + pc * 5 * 64 + lane;
                 const f32x4 mz = xb[4 * 64];
                 // mh / mz[0] are the ROUNDED exponent offsets m * log2(e) each half subtracted from its scores: the same numbers here, so
@@ -241,11 +264,11 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                 const float s0 = a0 * inv, s1 = a1 * inv;
                 f32x4 lg[NBA];
 #pragma unroll
-                for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int nb = 0; nb < NBA; ++nb) lg[nb] = bias[nb];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f32x4 o = sm.Rr[(pc * 16 + 4 * c + g) * 16 + q] + (Oh[c] * s0 + xb[c * 64] * s1);      // p[query][16c + 4g .. +3]
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, inq ? p_off0 + (unsigned)c * p_step : OOB, 0, ROLL_PNT);
+                    if (rowok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, vp, p_s + (unsigned)c * p_cstep, ROLL_PNT);
                     if (NB > 0) {
                         u32x2 oh, ol;
                         split4(o, oh, ol);
@@ -258,38 +281,31 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                         }
                     }
                 }
-                if (NB > 0) {       // logits: lg[nb][i] = class 16nb + 4g + i of query q
-                    const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
-                    const unsigned l_off0 = ((unsigned)n * (unsigned)p.n_cls * plane + pix) * 4u;
-                    float m = -INFINITY;
-#pragma unroll
-                    for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int cls = nb * 16 + 4 * g + i;
-                            lg[nb][i] += sm.Bfs[cls];
-                            m = fmaxf(m, cls < p.n_cls ? lg[nb][i] : -INFINITY);
-                        }
+                if (NB > 0) {       // logits: lg[nb][i] = class 16nb + 4g + i of query q (-inf for classes beyond n_cls)
                     if (p.log_softmax) {
+                        float m = -INFINITY;
+#pragma unroll
+                        for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) m = fmaxf(m, lg[nb][i]);
                         m = rows_max(m);
                         float z = 0.f;
 #pragma unroll
                         for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-                            for (int i = 0; i < 4; ++i) z += nb * 16 + 4 * g + i < p.n_cls ? __expf(lg[nb][i] - m) : 0.f;
+                            for (int i = 0; i < 4; ++i) z += __expf(lg[nb][i] - m);
                         z = rows_sum(z);
                         const float lse = m + __logf(z);
 #pragma unroll
                         for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
                     }
+                    if (rowok) {
 #pragma unroll
-                    for (int nb = 0; nb < NBA; ++nb)
+                        for (int nb = 0; nb < NBA; ++nb)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int cls = nb * 16 + 4 * g + i;
-                            const unsigned off = l_off0 + (unsigned)cls * plane * 4u;
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB, 0, ROLL_PNT);
-                        }
+                            for (int i = 0; i < 4; ++i)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, vl[nb][i], l_s, ROLL_PNT);
+                    }
                 }
             }
             // ---------------------------------------------------------------- H1: scores S[b][i] = q . key(16b + 4g + i) over this half's blocks, softmax
@@ -338,6 +354,7 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                         z += Sc[j][i];
                     }
                     P[j] = split4r(Sc[j]);
+                    P2[j] = u32x4{P[j].z, P[j].w, P[j].x, P[j].y};      // {lo | hi}: the second MFMA of a product swaps THIS operand, once per step
                 }
                 mh = ml; zh = rows_sum(z);
             }
@@ -369,9 +386,9 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < NBK; ++j) {
-                        const h16x8 pb = __builtin_bit_cast(h16x8, P[j]);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vh[c & 1][j], vl[c & 1][j]), pb, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pack8(vl[c & 1][j], vh[c & 1][j]), pb, acc, 0, 0, 0);
+                        const h16x8 va8 = pack8(vh[c & 1][j], vl[c & 1][j]);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va8, __builtin_bit_cast(h16x8, P[j]), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(va8, __builtin_bit_cast(h16x8, P2[j]), acc, 0, 0, 0);
                     }
                     Oh[c] = acc;
                     __builtin_amdgcn_sched_barrier(0);
@@ -434,6 +451,7 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ref[n]), 0, (int)p.ref_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr), 0, (int)p.lr_bytes, 0x00020000);
         const unsigned lr_img = (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + 16u * gcg;
+        const bool x_inner = x0 >= 3 && x0 + SW + 3 <= Wp;      // every record column of the strip inside the image
         // lr_up column taps of this lane's units: the same for every row of the strip
         bool l_lane[NLU > 0 ? NLU : 1];
         int lrr[NLU > 0 ? NLU : 1], lcc[NLU > 0 ? NLU : 1];
@@ -514,8 +532,9 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                         f32x4 a, b;
                         stencil2(sm.Wd + 160 + kcg * 10, row[0], row[1], row[2], row[3], a, b);
-                        sm.Vr[kcg * VPL + ((2 * k) & 7) * RW + kx] = split4r(in_a ? a : zero);
-                        sm.Vr[kcg * VPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(in_b ? b : zero);
+                        if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
+                        sm.Vr[kcg * VPL + ((2 * k) & 7) * RW + kx] = split4r(a);
+                        sm.Vr[kcg * VPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(b);
                     }
 #pragma unroll
                     for (int j = 0; j < 3; ++j) { row[0][j] = row[2][j]; row[1][j] = row[3][j]; }
@@ -564,8 +583,9 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                         f32x4 a, b;
                         stencil2(sm.Wd + kcg * 10, row[0], row[1], row[2], row[3], a, b);
-                        sm.Kr[kcg * KPL + ((2 * k) & 7) * RW + kx] = split4r(in_a ? a : zero);
-                        sm.Kr[kcg * KPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(in_b ? b : zero);
+                        if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
+                        sm.Kr[kcg * KPL + ((2 * k) & 7) * RW + kx] = split4r(a);
+                        sm.Kr[kcg * KPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(b);
                     }
                 }
             } else if (ROLE == ROLE_Q) {
@@ -671,7 +691,7 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
             if (cls < p.n_cls) wv4 = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)cls * CH + c * 16 + gg * 4);
             sm.Wfs[e] = __builtin_bit_cast(f32x4, split4r(wv4));
         }
-        if (tid < NBA * 16) sm.Bfs[tid] = tid < p.n_cls ? p.bf[tid] : 0.f;
+        if (tid < NBA * 16) sm.Bfs[tid] = tid < p.n_cls ? p.bf[tid] : -INFINITY;
     }
     __syncthreads();
 
