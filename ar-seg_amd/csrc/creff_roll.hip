@@ -54,8 +54,9 @@ constexpr int KSLOT = 8, VSLOT = 8;                  // ring rows = the 8 rows u
                                                      // in H1, value rows written in H1 and read in H2 -- nobody reads a ring while it is written
 constexpr int KPL = KSLOT * RW;                      // key records per channel-group plane: 176, a multiple of 16 (ds_read_b128 of one key
                                                      // block: the 4 groups g land in one 256-byte bank row side by side -- see creff_rr.hip)
-constexpr int VPL = VSLOT * RW + 4;                  // value records per plane: 180 = 4 mod 16 -- the transpose read takes 8 bytes of 8 keys from
-                                                     // each of 4 planes at once: planes 64 bytes (16 banks) apart, not on top of each other
+constexpr int VHALF = VSLOT * RW * 8;                // value records: per channel group a plane of the hi halves (8 bytes per record) and one of
+constexpr int VPL = (2 * VHALF + 64) / 16;           // the lo halves, groups 2880 bytes = 64 mod 256 apart -- a transpose read takes 8 bytes of 8
+                                                     // consecutive keys from each of 4 groups: 4 x 64 bytes side by side in the 256-byte bank row
 constexpr int WPL = GW + 1, LPL = LW + 1;            // plane pitch of the two stages in f32x4 (25 * 16 B = 16 mod 128, 19 * 16 B = 48 mod 128:
                                                      // the 8 lanes of a ds_write_b128 group -- 8 channel groups of one pixel -- cover all 32 banks)
 constexpr int NGP = 2 * GW, NLP = 2 * LW;            // staged pixels per iteration: 48 warped, 36 lr_up
@@ -155,6 +156,20 @@ __device__ __forceinline__ void stencil2(const f32x4 *w, const f32x4 (&r0)[3], c
     oa = a; ob = b;
 }
 
+// the same with the ten weight vectors already in registers (requested ahead of the barrier in front of the stencil: constants, so
+// their LDS round trip need not sit on the critical path of the half step that uses them)
+__device__ __forceinline__ void stencil2r(const f32x4 (&w)[10], const f32x4 (&r0)[3], const f32x4 (&r1)[3], const f32x4 (&r2)[3],
+                                          const f32x4 (&r3)[3], f32x4 &oa, f32x4 &ob) {
+    f32x4 a = w[9], b = a;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a = fma4(w[j], r0[j], a); b = fma4(w[j], r1[j], b); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a = fma4(w[3 + j], r1[j], a); b = fma4(w[3 + j], r2[j], b); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a = fma4(w[6 + j], r2[j], a); b = fma4(w[6 + j], r3[j], b); }
+    oa = a; ob = b;
+}
+
 #ifdef ROLL_TIMING
 // dev builds only: every wave accumulates the shader-clock ticks of its four segments per iteration (H1 work, wait at barrier A, H2 work,
 // wait at barrier B) and adds them to dbg[8 * wave + i] when it is done (tools/time_roll.py)
@@ -249,11 +264,12 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
         for (int t = T_FIRST; t <= S + 5; ++t) {
             const int s = t - 5;
             u32x4 P[NBK], P2[NBK];
+            f32x4 lgc[NBA];                              // logits of step s - 1 before the log-softmax: finished in H2 (this wave's H1 is its longer half)
             // ---------------------------------------------------------------- H1 (KH 0 first): merge the halves of step s - 1, residual, classifier, stores
             if (KH == 0 && s >= 1) {
                 // rows of the step: ys + 2(s-1), + 1; the second one may lie below the image (odd height): those lanes store nothing
                 const bool rowok = qy == 0 || ys + 2 * (s - 1) + 1 < Hp;
-                const unsigned p_s = p_unit + (unsigned)(s - 1) * p_rstep, l_s = l_unit + (unsigned)(s - 1) * l_rstep;
+                const unsigned p_s = p_unit + (unsigned)(s - 1) * p_rstep;
                 const f32x4 *xb = sm.Xb + pc * 5 * 64 + lane;
                 const f32x4 mz = xb[4 * 64];
                 // mh / mz[0] are the ROUNDED exponent offsets m * log2(e) each half subtracted from its scores: the same numbers here, so
@@ -262,49 +278,19 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                 const float a0 = __builtin_amdgcn_exp2f(mh - M), a1 = __builtin_amdgcn_exp2f(mz[0] - M);
                 const float inv = 1.0f / (zh * a0 + mz[1] * a1);
                 const float s0 = a0 * inv, s1 = a1 * inv;
-                f32x4 lg[NBA];
-#pragma unroll
-                for (int nb = 0; nb < NBA; ++nb) lg[nb] = bias[nb];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f32x4 o = sm.Rr[(pc * 16 + 4 * c + g) * 16 + q] + (Oh[c] * s0 + xb[c * 64] * s1);      // p[query][16c + 4g .. +3]
                     if (rowok) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), p_rsrc, vp, p_s + (unsigned)c * p_cstep, ROLL_PNT);
                     if (NB > 0) {
-                        u32x2 oh, ol;
-                        split4(o, oh, ol);
-                        const h16x8 o1 = pack8(oh, ol), o2 = pack8(ol, oh);
+                        const u32x4 os = split4r(o);
+                        const h16x8 o1 = __builtin_bit_cast(h16x8, os), o2 = __builtin_bit_cast(h16x8, u32x4{os.z, os.w, os.x, os.y});
 #pragma unroll
                         for (int nb = 0; nb < NBA; ++nb) {
                             const h16x8 wa = __builtin_bit_cast(h16x8, sm.Wfs[(c * 4 + g) * NBA * 16 + nb * 16 + q]);
-                            lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o1, lg[nb], 0, 0, 0);
-                            lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o2, lg[nb], 0, 0, 0);
+                            lgc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o1, c == 0 ? bias[nb] : lgc[nb], 0, 0, 0);
+                            lgc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, o2, lgc[nb], 0, 0, 0);
                         }
-                    }
-                }
-                if (NB > 0) {       // logits: lg[nb][i] = class 16nb + 4g + i of query q (-inf for classes beyond n_cls)
-                    if (p.log_softmax) {
-                        float m = -INFINITY;
-#pragma unroll
-                        for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) m = fmaxf(m, lg[nb][i]);
-                        m = rows_max(m);
-                        float z = 0.f;
-#pragma unroll
-                        for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) z += __expf(lg[nb][i] - m);
-                        z = rows_sum(z);
-                        const float lse = m + __logf(z);
-#pragma unroll
-                        for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
-                    }
-                    if (rowok) {
-#pragma unroll
-                        for (int nb = 0; nb < NBA; ++nb)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i)
-                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, vl[nb][i], l_s, ROLL_PNT);
                     }
                 }
             }
@@ -361,26 +347,59 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
             RT(0);
             wg_sync();
             RT(1);
+            // ---------------------------------------------------------------- H2 (KH 0 first): log-softmax + logits stores of step s - 1
+            if (KH == 0 && NB > 0 && s >= 1) {
+                const bool rowok = qy == 0 || ys + 2 * (s - 1) + 1 < Hp;
+                const unsigned l_s = l_unit + (unsigned)(s - 1) * l_rstep;
+                f32x4 lg[NBA];
+#pragma unroll
+                for (int nb = 0; nb < NBA; ++nb) lg[nb] = lgc[nb];
+                // logits: lg[nb][i] = class 16nb + 4g + i of query q (-inf for classes beyond n_cls)
+                if (p.log_softmax) {
+                    float m = -INFINITY;
+#pragma unroll
+                    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) m = fmaxf(m, lg[nb][i]);
+                    m = rows_max(m);
+                    float z = 0.f;
+#pragma unroll
+                    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) z += __expf(lg[nb][i] - m);
+                    z = rows_sum(z);
+                    const float lse = m + __logf(z);
+#pragma unroll
+                    for (int nb = 0; nb < NBA; ++nb) lg[nb] -= lse;
+                }
+                if (rowok) {
+#pragma unroll
+                    for (int nb = 0; nb < NBA; ++nb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(lg[nb][i]), l_rsrc, vl[nb][i], l_s, ROLL_PNT);
+                }
+            }
             // ---------------------------------------------------------------- H2: P.V over this half's blocks (un-normalised)
             if (s >= 0 && s < S) {
                 // byte offset of the value record of (block b, this lane's key) in a channel-group plane
                 const int b8 = (2 * s) & 7;
                 unsigned vrec[NBK];
 #pragma unroll
-                for (int j = 0; j < NBK; ++j) vrec[j] = (unsigned)((((vky[j] + b8) & 7) * RW + vkx[j]) * 16);
+                for (int j = 0; j < NBK; ++j) vrec[j] = (unsigned)((((vky[j] + b8) & 7) * RW + vkx[j]) * 8);
                 // value operands one chunk ahead, as the key records above
                 u32x2 vh[2][NBK], vl[2][NBK];
                 {
                     const unsigned char *va = reinterpret_cast<const unsigned char *>(sm.Vr + (q & 3) * VPL);
 #pragma unroll
-                    for (int j = 0; j < NBK; ++j) { vh[0][j] = lds_tr16(va + vrec[j]); vl[0][j] = lds_tr16(va + vrec[j] + 8); }
+                    for (int j = 0; j < NBK; ++j) { vh[0][j] = lds_tr16(va + vrec[j]); vl[0][j] = lds_tr16(va + VHALF + vrec[j]); }
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     if (c < 3) {
                         const unsigned char *va = reinterpret_cast<const unsigned char *>(sm.Vr + (4 * (c + 1) + (q & 3)) * VPL);
 #pragma unroll
-                        for (int j = 0; j < NBK; ++j) { vh[(c + 1) & 1][j] = lds_tr16(va + vrec[j]); vl[(c + 1) & 1][j] = lds_tr16(va + vrec[j] + 8); }
+                        for (int j = 0; j < NBK; ++j) { vh[(c + 1) & 1][j] = lds_tr16(va + vrec[j]); vl[(c + 1) & 1][j] = lds_tr16(va + VHALF + vrec[j]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -473,6 +492,9 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         // ROLE_KV: the four warp rows under the two record rows being produced (rows 0, 1: the window; 2, 3: staged this iteration);
         // ROLE_Q: rows 0, 1 = the window of lr_up rows
         f32x4 row[ROLE == ROLE_KV ? 4 : 2][3], gw = {0.f, 0.f, 0.f, 0.f}, savA = {0.f, 0.f, 0.f, 0.f};
+        f32x4 wreg[10];                              // the depthwise weights of the NEXT half step's stencil (ROLE_KV: key in H2 / value in H1)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) wreg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         unsigned mvv = 0u, go = 0u, pft[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
         float ngx = 0.f, ngy = 0.f;
 #pragma unroll
@@ -482,6 +504,27 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
 
         for (int t = T_FIRST; t <= S + 5; ++t) {
             // ================================================================ H1
+            if (ROLE == ROLE_KV) {
+                // ---- value records of rows rho = 2k, 2k + 1 (k = t - 2) from the four warp rows the key conv of H2(t-1) used (weights requested at
+                // the end of H2(t-1)); then the window moves on
+                if (kv_ok && t >= 1 && t <= S + 4) {
+                    if (t >= 2) {
+                        const int k = t - 2, r0 = ys - 3 + 2 * k;
+                        const bool col_in = (unsigned)(x0 - 3 + kx) < (unsigned)Wp;
+                        const bool in_a = col_in && (unsigned)r0 < (unsigned)Hp, in_b = col_in && (unsigned)(r0 + 1) < (unsigned)Hp;
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        f32x4 a, b;
+                        stencil2r(wreg, row[0], row[1], row[2], row[3], a, b);
+                        if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
+                        u32x2 *vdst = reinterpret_cast<u32x2 *>(reinterpret_cast<unsigned char *>(sm.Vr) + kcg * (VPL * 16)) + ((2 * k) & 7) * RW + kx;
+                        const u32x4 ra = split4r(a), rb = split4r(b);
+                        vdst[0] = u32x2{ra.x, ra.y}; vdst[VHALF / 8] = u32x2{ra.z, ra.w};
+                        vdst[RW] = u32x2{rb.x, rb.y}; vdst[VHALF / 8 + RW] = u32x2{rb.z, rb.w};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) { row[0][j] = row[2][j]; row[1][j] = row[3][j]; }
+                }
+            }
             // ---- gather t: the four taps of this lane's pixel (tap offsets read in H1(t-1); the lines were touched by the tap wave in H2(t-2),
             // so these come from the L2: no load of a compute wave is in flight across a barrier -- hipcc's s_waitcnt bookkeeping otherwise
             // makes the LDS reads of H2 wait for them)
@@ -522,24 +565,6 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                 lv[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx0[i] : OOB, 0, 0));
                 lv[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx1[i] : OOB, 0, 0));
             }
-            if (ROLE == ROLE_KV) {
-                // ---- value records of rows rho = 2k, 2k + 1 (k = t - 2) from the four warp rows the key conv of H2(t-1) used; then the window moves on
-                if (kv_ok && t >= 1 && t <= S + 4) {
-                    if (t >= 2) {
-                        const int k = t - 2, r0 = ys - 3 + 2 * k;
-                        const bool col_in = (unsigned)(x0 - 3 + kx) < (unsigned)Wp;
-                        const bool in_a = col_in && (unsigned)r0 < (unsigned)Hp, in_b = col_in && (unsigned)(r0 + 1) < (unsigned)Hp;
-                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-                        f32x4 a, b;
-                        stencil2(sm.Wd + 160 + kcg * 10, row[0], row[1], row[2], row[3], a, b);
-                        if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
-                        sm.Vr[kcg * VPL + ((2 * k) & 7) * RW + kx] = split4r(a);
-                        sm.Vr[kcg * VPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(b);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) { row[0][j] = row[2][j]; row[1][j] = row[3][j]; }
-                }
-            }
             // ---- sampling position of gather t + 2 (warp rows ys - 4 + 2(t+2), +1), fp64 like the reference; the MV was requested in H2(t-1)
             if (ROLE == ROLE_AUX && tap_lane && t >= -2 && t <= S + 1) {
                 const int gy = ys + 2 * t + trr, gx = x0 - 4 + tcc;
@@ -566,6 +591,10 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                 sm.Ws[(grr * 16 + gcg) * WPL + gcc] = acc;
             }
             if (t >= -1 && t <= S + 2) { go = sm.TapO[gpx]; gw = sm.TapW[gpx]; }
+            if (ROLE == ROLE_KV) {
+#pragma unroll
+                for (int j = 0; j < 10; ++j) wreg[j] = sm.Wd[kcg * 10 + j];
+            }
             RT(0);
             wg_sync();
             RT(1);
@@ -582,12 +611,14 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                         const bool in_a = col_in && (unsigned)r0 < (unsigned)Hp, in_b = col_in && (unsigned)(r0 + 1) < (unsigned)Hp;
                         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
                         f32x4 a, b;
-                        stencil2(sm.Wd + kcg * 10, row[0], row[1], row[2], row[3], a, b);
+                        stencil2r(wreg, row[0], row[1], row[2], row[3], a, b);
                         if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
                         sm.Kr[kcg * KPL + ((2 * k) & 7) * RW + kx] = split4r(a);
                         sm.Kr[kcg * KPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(b);
                     }
                 }
+#pragma unroll
+                for (int j = 0; j < 10; ++j) wreg[j] = sm.Wd[160 + kcg * 10 + j];
             } else if (ROLE == ROLE_Q) {
                 // ---- residual records of step t - 5: lr_up at the query pixels (row A saved in H2(t-1), row B still in the window)
                 if (t >= 5 && t <= S + 4) {

@@ -796,7 +796,8 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     if (seg_rows < 0) return ARSEG_EINVAL;
     for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
-    if (impl != ARSEG_CREFF_WARP_TILES)           // the rolling kernel (creff_roll.hip) is the default
+    // the rolling kernel (creff_roll.hip) is the default; with more than 16 classes its head spills registers: the tile kernel then
+    if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16)))
         return arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
                                        log_softmax, N, Hp, Wp, hp, wp, seg_rows, arseg_stream(stream));
     RRParams p;
