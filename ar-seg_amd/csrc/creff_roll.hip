@@ -32,6 +32,9 @@
 #ifndef ROLL_PNT
 #define ROLL_PNT 2            // cache policy of the p / logits stores: 2 = nontemporal
 #endif
+#ifndef ROLL_LRTAB
+#define ROLL_LRTAB 0          // 1: the row taps of the lr_up rows come from a table the tap wave writes (measured slower: an LDS round trip in
+#endif                        // front of the lr loads, and the tap wave is the longest of H2)
 #ifndef ROLL_CPRIO
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
 #endif
@@ -69,8 +72,9 @@ constexpr int Q_OFF = LS_OFF + 2 * 16 * LPL * 16;    // 112,640  query records [
 constexpr int R_OFF = Q_OFF + 2 * 16 * 16 * 16;      // 120,832  residual records lr_up(query) [2 patches][16 groups][16 queries] fp32 x 4
 constexpr int XB_OFF = R_OFF + 2 * 16 * 16 * 16;     // 129,024  partials of the kh-1 waves [2 patches][4 chunks + {m, z}][64 lanes]
 constexpr int TW_OFF = XB_OFF + 2 * 5 * 64 * 16;     // 139,264  [48] {ex, wx, ey, wy} with the tap validity folded in
-constexpr int TO_OFF = TW_OFF + NGP * 16;            // 140,032  [48] pixel index of the NW tap | dx << 30 | dy << 31 (clamped taps)
-constexpr int WD_OFF = TO_OFF + NGP * 4;             // 140,224  depthwise weights [key | value | query][16 groups][9 taps + bias]
+constexpr int TO_OFF = TW_OFF + NGP * 16;            //          [48] byte offsets of the four (clamped) taps of a pixel: NW, NE, SW, SE
+constexpr int LR_OFF = TO_OFF + NGP * 16;            //          [2] lr taps of the two lr_up rows of an iteration {row 0 bytes, row 1 bytes, w0, w1}
+constexpr int WD_OFF = LR_OFF + 2 * 16;              //          depthwise weights [key | value | query][16 groups][9 taps + bias]
 constexpr int WF_OFF = WD_OFF + 3 * 160 * 16;        // 147,904  classifier records [4 chunks][4 groups][32] {4 hi | 4 lo}
 constexpr int BF_OFF = WF_OFF + 4 * 4 * 32 * 16;     // 156,096  classifier bias [32]
 constexpr int SMEM_BYTES = BF_OFF + 32 * 4;          // 156,224 <= 163,840
@@ -194,7 +198,7 @@ __device__ __forceinline__ void stencil2r(const f32x4 (&w)[10], const f32x4 (&r0
 struct Smem {
     u32x4 *Kr, *Vr, *Qr;
     f32x4 *Ws, *Ls, *Rr, *Xb, *TapW, *Wd, *Wfs;
-    unsigned *TapO;
+    u32x4 *TapO, *LrRow;
     float *Bfs;
 };
 struct Sched { int per_img, u_first, u_last, u_step; };      // this workgroup's units: u_first, u_first + u_step, ... < u_last
@@ -488,6 +492,7 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
             const float inx = (unsigned)gx < (unsigned)Wp ? 1.f : 0.f;
             lwx0[i] = (1.f - m) * inx; lwx1[i] = m * inx;
             lx0[i] = (unsigned)j0 * (CH * 4u); lx1[i] = (unsigned)j1 * (CH * 4u);
+            if (!l_lane[i]) { lx0[i] = OOB - lr_img; lx1[i] = OOB - lr_img; }      // (wave 13: no unit -- with the row offset still beyond the buffer)
         }
         // ROLE_KV: the four warp rows under the two record rows being produced (rows 0, 1: the window; 2, 3: staged this iteration);
         // ROLE_Q: rows 0, 1 = the window of lr_up rows
@@ -495,7 +500,8 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         f32x4 wreg[10];                              // the depthwise weights of the NEXT half step's stencil (ROLE_KV: key in H2 / value in H1)
 #pragma unroll
         for (int j = 0; j < 10; ++j) wreg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned mvv = 0u, go = 0u, pft[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        unsigned mvv = 0u, pft[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+        u32x4 go = {0u, 0u, 0u, 0u};
         float ngx = 0.f, ngy = 0.f;
 #pragma unroll
         for (int i = 0; i < (ROLE == ROLE_KV ? 4 : 2); ++i)
@@ -534,36 +540,38 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
 #else
             const bool g_on = t >= 0 && t <= S + 3;
 #endif
-            {
-                const unsigned a = g_on ? (go & 0x3FFFFFFFu) * (CH * 4u) + 16u * gcg : OOB;
-                const unsigned dxo = (go & 0x40000000u) ? CH * 4u : 0u, dyo = (go & 0x80000000u) ? (unsigned)Wp * (CH * 4u) : 0u;
-                gv[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, a, 0, 0));
-                gv[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dxo : OOB, 0, 0));
-                gv[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dyo : OOB, 0, 0));
-                gv[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, g_on ? a + dyo + dxo : OOB, 0, 0));
-            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k)      // (outside [0, S+3] the offsets are stale but valid: the values are not used)
+                gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, go[k] + 16u * gcg, 0, 0));
             // ---- lr_up rows ys + 2t - 7, ys + 2t - 6 (+1 halo column each side): the bilinear taps (lines touched by wave 12 in H2(t-2))
+#ifdef ROLL_NOLR
+            const bool l_on = false;
+#else
             const bool l_on = t >= 3 && t <= S + 3;
+#endif
             f32x4 lv[NLU > 0 ? NLU : 1][4];
             float lwy0[NLU > 0 ? NLU : 1], lwy1[NLU > 0 ? NLU : 1];
-#pragma unroll
-            for (int i = 0; i < NLU; ++i) {
-#ifdef ROLL_NOLR
-                const bool l_do = false;
+            {                                                        // (unconditional: hipcc spills registers that loads define under a branch;
+#pragma unroll                                                       //  outside [3, S+3] the table rows are stale, the values unused)
+                for (int i = 0; i < NLU; ++i) {
+#if ROLL_LRTAB
+                    const u32x4 rt = sm.LrRow[lrr[i]];              // the row taps of the iteration (tap wave, H2(t-1))
+                    lwy0[i] = __uint_as_float(rt.z); lwy1[i] = __uint_as_float(rt.w);
+                    const unsigned r0 = lr_img + rt.x, r1 = lr_img + rt.y;
 #else
-                const bool l_do = l_on && l_lane[i];
+                    const int gy = ys + 2 * t - 7 + lrr[i];
+                    int i0, i1; float l;
+                    arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, i0, i1, l);
+                    l = fminf(fmaxf(l, 0.f), 1.f);
+                    const float iny = (unsigned)gy < (unsigned)Hp ? 1.f : 0.f;
+                    lwy0[i] = (1.f - l) * iny; lwy1[i] = l * iny;
+                    const unsigned r0 = lr_img + (unsigned)(i0 * p.wp) * (CH * 4u), r1 = lr_img + (unsigned)(i1 * p.wp) * (CH * 4u);
 #endif
-                const int gy = ys + 2 * t - 7 + lrr[i];
-                int i0, i1; float l;
-                arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, i0, i1, l);
-                l = fminf(fmaxf(l, 0.f), 1.f);
-                const float iny = (unsigned)gy < (unsigned)Hp ? 1.f : 0.f;
-                lwy0[i] = (1.f - l) * iny; lwy1[i] = l * iny;
-                const unsigned r0 = lr_img + (unsigned)(i0 * p.wp) * (CH * 4u), r1 = lr_img + (unsigned)(i1 * p.wp) * (CH * 4u);
-                lv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx0[i] : OOB, 0, 0));
-                lv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r0 + lx1[i] : OOB, 0, 0));
-                lv[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx0[i] : OOB, 0, 0));
-                lv[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, l_do ? r1 + lx1[i] : OOB, 0, 0));
+                    lv[i][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, r0 + lx0[i], 0, 0));
+                    lv[i][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, r0 + lx1[i], 0, 0));
+                    lv[i][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, r1 + lx0[i], 0, 0));
+                    lv[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, r1 + lx1[i], 0, 0));
+                }
             }
             // ---- sampling position of gather t + 2 (warp rows ys - 4 + 2(t+2), +1), fp64 like the reference; the MV was requested in H2(t-1)
             if (ROLE == ROLE_AUX && tap_lane && t >= -2 && t <= S + 1) {
@@ -645,22 +653,28 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                 if (tap_lane && t >= -2 && t <= S + 1) {
                     const int gy = ys + 2 * t + trr, gx = x0 - 4 + tcc;
                     f32x4 w = {0.f, 0.f, 0.f, 0.f};
-                    unsigned o = 0;
+                    u32x4 o = {0u, 0u, 0u, 0u};
                     if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp) {      // outside the image the warped feature is zero (conv padding)
                         const Taps tp = make_taps(ngx, ngy, Hp, Wp);
                         const int xa = min(max(tp.x0, 0), Wp - 1), xc = min(max(tp.x0 + 1, 0), Wp - 1);
                         const int ya = min(max(tp.y0, 0), Hp - 1), yc = min(max(tp.y0 + 1, 0), Hp - 1);
-                        o = (unsigned)(ya * Wp + xa) | ((unsigned)(xc - xa) << 30) | ((unsigned)(yc - ya) << 31);
+                        o = u32x4{(unsigned)(ya * Wp + xa), (unsigned)(ya * Wp + xc), (unsigned)(yc * Wp + xa), (unsigned)(yc * Wp + xc)} * (CH * 4u);
                         w = f32x4{tp.vx0 ? tp.ex : 0.f, tp.vx1 ? tp.wx : 0.f, tp.vy0 ? tp.ey : 0.f, tp.vy1 ? tp.wy : 0.f};
                     }
                     sm.TapW[tl] = w; sm.TapO[tl] = o;
                     // touch the eight 128-byte lines of the four tap pixels: the gather lanes read them one and a half iterations from now
                     asm volatile("" :: "v"(pft[0]), "v"(pft[1]), "v"(pft[2]), "v"(pft[3]), "v"(pft[4]), "v"(pft[5]), "v"(pft[6]), "v"(pft[7]));
-                    const unsigned a = (o & 0x3FFFFFFFu) * (CH * 4u);
-                    const unsigned dxo = (o & 0x40000000u) ? CH * 4u : 0u, dyo = (o & 0x80000000u) ? (unsigned)Wp * (CH * 4u) : 0u;
 #pragma unroll
-                    for (int i = 0; i < 8; ++i)
-                        pft[i] = __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, a + ((i & 1) ? 128u : 0u) + ((i & 2) ? dxo : 0u) + ((i & 4) ? dyo : 0u), 0, 0);
+                    for (int i = 0; i < 8; ++i) pft[i] = __builtin_amdgcn_raw_buffer_load_b32(g_rsrc, o[i >> 1] + ((i & 1) ? 128u : 0u), 0, 0);
+                }
+                // ---- lr row taps of iteration t + 1 (lr_up rows ys + 2t - 5, ys + 2t - 4): lanes 48, 49 of the tap wave
+                if (ROLL_LRTAB && wave == 13 && (tl == NGP || tl == NGP + 1) && t >= 2 && t <= S + 2) {
+                    const int gy = ys + 2 * t - 5 + (tl - NGP);
+                    int i0, i1; float l;
+                    arseg_src_index(p.sy, min(max(gy, 0), Hp - 1), true, p.hp, i0, i1, l);
+                    l = fminf(fmaxf(l, 0.f), 1.f);
+                    const float iny = (unsigned)gy < (unsigned)Hp ? 1.f : 0.f;
+                    sm.LrRow[tl - NGP] = u32x4{(unsigned)(i0 * p.wp) * (CH * 4u), (unsigned)(i1 * p.wp) * (CH * 4u), __float_as_uint((1.f - l) * iny), __float_as_uint(l * iny)};
                 }
                 // ---- motion vectors of gather t + 3 (identity-resize case: one int16 pair per pixel)
                 if (tap_lane && mv_ident && t <= S) {
@@ -702,7 +716,8 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     sm.Ws = reinterpret_cast<f32x4 *>(smem + WS_OFF); sm.Ls = reinterpret_cast<f32x4 *>(smem + LS_OFF);
     sm.Qr = reinterpret_cast<u32x4 *>(smem + Q_OFF); sm.Rr = reinterpret_cast<f32x4 *>(smem + R_OFF);
     sm.Xb = reinterpret_cast<f32x4 *>(smem + XB_OFF); sm.TapW = reinterpret_cast<f32x4 *>(smem + TW_OFF);
-    sm.TapO = reinterpret_cast<unsigned *>(smem + TO_OFF); sm.Wd = reinterpret_cast<f32x4 *>(smem + WD_OFF);
+    sm.TapO = reinterpret_cast<u32x4 *>(smem + TO_OFF); sm.LrRow = reinterpret_cast<u32x4 *>(smem + LR_OFF);
+    sm.Wd = reinterpret_cast<f32x4 *>(smem + WD_OFF);
     sm.Wfs = reinterpret_cast<f32x4 *>(smem + WF_OFF);        // [4 chunks][4 groups][NBA*16]
     sm.Bfs = reinterpret_cast<float *>(smem + BF_OFF);
 

@@ -325,6 +325,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
+// The per-image second weight operand of arseg_gemm_x3_cat_fwd for the folded PSP bottleneck (model/pspnet.py:14-31), straight from the pyramid
+// terms: w2[n][co][k] = t[n][k][co] * unscale[co] for k < rows, 0 for rows <= k < 64, written as split rows (one thread = 4 consecutive k).
+__global__ __launch_bounds__(256) void psp_w2_split_kernel(const float *__restrict__ t, const float *__restrict__ unscale, unsigned char *__restrict__ out,
+                                                           int N, int rows, int Cout) {
+    const long long total = (long long)N * Cout * 16;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int k = (int)(idx & 15) * 4;
+        const long long nc = idx >> 4;
+        const int co = (int)(nc % Cout);
+        const long long n = nc / Cout;
+        const float f = unscale[co];
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k + j < rows ? t[(n * rows + k + j) * Cout + co] * f : 0.f;
+        unsigned h01, h23, l01, l23;
+        arseg_split_f16(v, h01, h23, l01, l23);
+        unsigned char *o = out + nc * 256 + (k >> 5) * 128 + (k & 31) * 2;
+        *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+        *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
+    }
+}
+
 template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
 int launch_x3(GX3Params &p, hipStream_t hs) {
     constexpr int BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
@@ -352,6 +374,18 @@ int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
 }
 
 }  // namespace
+
+extern "C" int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(t); ARSEG_CHECK_PTR(unscale); ARSEG_CHECK_PTR(out);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(rows); ARSEG_CHECK_POS(Cout);
+    if (rows > 64) return ARSEG_EUNSUPPORTED;
+    if (!ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    const long long total = (long long)N * Cout * 16;
+    const long long blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(psp_w2_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, arseg_stream(stream), t, unscale,
+                       reinterpret_cast<unsigned char *>(out), N, rows, Cout);
+    return arseg_launch_status();
+}
 
 extern "C" int arseg_split_rows_fwd(const float *in, long long in_ld, void *out, long long rows, int K, float mul, void *range_flag,
                                     float range_limit, arseg_stream_t stream) {

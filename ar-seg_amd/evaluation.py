@@ -55,7 +55,7 @@ class EvalConstRes(object):
         self.scale = scale
 
     def __call__(self, net, dl, n_classes):
-        return _range_safe(lambda: self._run(net, dl, n_classes), dl)
+        return _range_safe(lambda: self._run(net, dl, n_classes), dl, n_classes)
 
     def _run(self, net, dl, n_classes):
         hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
@@ -68,25 +68,35 @@ class EvalConstRes(object):
                 imgs = _resize_frames(imgs, h, w)
             logits = net(imgs)[0]
             _, hist = ops.argmax_confusion(logits, label, label.shape[-2], label.shape[-1], hist, self.ignore_label, want_pred=False)
-        return _miou(hist, n_classes)
+        return hist
 
 
-def _range_safe(run, dl):
-    """Runs an evaluation pass; if the split-fp16 convs met an activation outside their operand range (the sticky device word of
-    ops.range_tripped -- read once, after the pass, which ends in a host read anyway), the pass is repeated on the fp32 matrix-core back
-    end.  A one-shot iterator cannot be replayed: that raises instead of returning a possibly clamped result."""
+def _range_safe(run, dl, n_classes, reset=None):
+    """Runs an evaluation pass (``run()`` returns this rank's confusion matrix); if the split-fp16 convs met an activation outside their
+    operand range (the sticky device word of ops.range_tripped -- read once, after the pass, which ends in a host read anyway), the pass is
+    repeated on the fp32 matrix-core back end.  With torch.distributed initialised the decision is COLLECTIVE (max of the ranks' flags: a
+    rank that did not trip repeats as well, so every rank issues the same collectives) and the histogram is all-reduced once, on the final
+    pass only (evaluation.py:134-135).  A one-shot iterator cannot be replayed: that raises instead of returning a possibly clamped result."""
     ops.range_tripped()                      # clear what earlier launches left
-    result = run()
-    if not ops.range_tripped():
-        return result
-    if iter(dl) is dl:
-        raise _lib.ArsegError("an activation left the split-fp16 operand range (|x| > 65504) and the data iterator cannot be replayed: "
-                              "evaluate with ops.set_conv_math('f32')")
-    prev = ops.set_conv_math("f32")
-    try:
-        return run()
-    finally:
-        ops.set_conv_math(prev)
+    hist = run()
+    tripped = bool(ops.range_tripped())
+    multi = dist.is_available() and dist.is_initialized()
+    if multi:
+        flag = torch.tensor([1.0 if tripped else 0.0], device=hist.device)
+        dist.all_reduce(flag, dist.ReduceOp.MAX)
+        tripped = bool(flag.item() > 0)
+    if tripped:
+        if hasattr(dl, "__next__") or not hasattr(dl, "__iter__"):          # an iterator, not a re-iterable loader
+            raise _lib.ArsegError("an activation left the split-fp16 operand range (|x| > 65504) and the data iterator cannot be replayed: "
+                                  "evaluate with ops.set_conv_math('f32')")
+        if reset is not None:
+            reset()                          # per-pass counters start again
+        prev = ops.set_conv_math("f32")
+        try:
+            hist = run()
+        finally:
+            ops.set_conv_math(prev)
+    return _miou(hist, n_classes)
 
 
 def _resize_frames(imgs, h, w):
@@ -118,7 +128,12 @@ class EvalAlterRes(object):
         self.hr_forwards = 0
 
     def __call__(self, highres_net, net, dl, n_classes):
-        return _range_safe(lambda: self._run(highres_net, net, dl, n_classes), dl)
+        first = self.hr_forwards
+
+        def reset():
+            self.hr_forwards = first
+
+        return _range_safe(lambda: self._run(highres_net, net, dl, n_classes), dl, n_classes, reset)
 
     def _run(self, highres_net, net, dl, n_classes):
         hist = torch.zeros((n_classes, n_classes), dtype=torch.int64, device="cuda")
@@ -143,7 +158,7 @@ class EvalAlterRes(object):
             out_p = lr_net.forward_phase1(imgs)[-1]                                          # :190-191
             out, _ = lr_net.forward_phase2(out_p, highres_ref_p)                             # :193
             _, hist = ops.argmax_confusion(out, label, label.shape[-2], label.shape[-1], hist, self.ignore_label, want_pred=False)
-        return _miou(hist, n_classes)
+        return hist
 
 
 def alter_res_step_fast(lr_net, ref_p_nhwc, img, mv_q, scale=0.5):

@@ -56,14 +56,19 @@ class GopGraph:
             self.outputs = outs
         torch.cuda.synchronize()
 
-    def replay(self) -> List[torch.Tensor]:
-        """Enqueue ``lanes`` GOP steps; returns their (static) output tensors."""
+    def replay(self, join: bool = True) -> List[torch.Tensor]:
+        """Enqueue ``lanes`` GOP steps; returns their (static) output tensors.  join (independent mode): the caller's stream waits for every
+        lane, so the outputs may be read -- and the static inputs refilled with ``copy_`` -- in stream order right after the call.
+        ``join=False`` leaves the lanes running on their private streams (back-to-back replays keep the cross-step overlap: what the
+        throughput benchmark wants); the caller then orders itself with ``synchronize()`` before it touches inputs or outputs."""
         if self.independent:
             cur = torch.cuda.current_stream()
             for g, st in zip(self.graphs, self._streams):
                 st.wait_stream(cur)                     # (work enqueued before this call, e.g. an input refill on the caller's stream)
                 with torch.cuda.stream(st):
                     g.replay()
+            if join:
+                self.synchronize()
             return self.outputs
         self.graph.replay()
         return self.outputs

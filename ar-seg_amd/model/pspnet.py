@@ -56,7 +56,7 @@ class PSPModule(HipModule):
         # pooling launches themselves: a torch.zeros here was a fill launch per forward, 2.4 % of the traced GPU time in round 2)
         pooled = ops.psp_pool_matrix(feats, self.sizes)
         t = ops.conv2d(pooled, pk["prior"])                                   # [N, rows, 1, 1024]: all levels, one launch
-        if ops.gemm_x3_enabled() and rows <= 64 and C % 32 == 0 and not ops.is16(feats):
+        if ops.gemm_x3_enabled() and rows <= 64 and C % 32 == 0 and not ops.is16(feats) and ops.psp_x3_foldable(pk["feat"]):
             # the pyramid sum as two more K steps of the bottleneck GEMM (interpolation matrix x per-image pyramid terms), result in split rows
             return ops.psp_bottleneck_x3(feats, t.reshape(N, rows, -1), pk["feat"], self.sizes)
         prior = ops.psp_prior_sum(t.reshape(N, rows, -1), self.sizes, h, w)   # sum_s upsample(t_s), F.upsample default mode

@@ -80,13 +80,23 @@ config = Config.from_env()
 
 def configure(**kw):
     """Change knobs of ``ops.config`` at run time (names as in Config); returns the previous values of the ones changed."""
-    prev = {}
-    for k, v in kw.items():
+    for k, v in kw.items():          # validate everything before anything changes
         if not hasattr(config, k):
             raise _lib.ArsegError(f"unknown configuration key {k!r}")
-        prev[k] = getattr(config, k)
+        if k == "conv_math" and v not in _MATH_NAMES:
+            raise _lib.ArsegError(f"conv_math must be one of {sorted(_MATH_NAMES)}, got {v!r}")
+        if k == "creff_warp_impl" and v not in ("", "roll", "tiles"):
+            raise _lib.ArsegError(f"creff_warp_impl must be '', 'roll' or 'tiles', got {v!r}")
+    prev = {k: getattr(config, k) for k in kw}
+    for k, v in kw.items():
         setattr(config, k, v)
-    _apply_config()
+    try:
+        _apply_config()
+    except Exception:
+        for k, v in prev.items():
+            setattr(config, k, v)
+        _apply_config()
+        raise
     return prev
 
 
@@ -98,7 +108,11 @@ _profile = None
 
 class profile:
     """``with ops.profile() as prof: ...`` records (op name, algorithmic flops, algorithmic bytes, ms) per launch.
-    Events are recorded on torch's current stream, which is the stream handed to the library."""
+    Events are recorded on torch's current stream, which is the stream handed to the library.  ``only`` = a set of op names: time
+    just those (the others launch without events, so that concurrent streams keep the GPU as busy as in an un-instrumented run)."""
+
+    def __init__(self, only=None):
+        self.only = None if only is None else frozenset(only)
 
     def __enter__(self):
         global _profile
@@ -149,7 +163,7 @@ _layer_tag = None      # set by conv2d while it launches on behalf of one layer 
 
 
 def _launch(name, fn, *args, flops=0, nbytes=0):
-    if _profile is None:
+    if _profile is None or (_profile.only is not None and name not in _profile.only):
         check(fn(*args), name)
         return
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -592,10 +606,13 @@ _PLAN_FILE = config.conv_plan_file       # optional: persist tuned plans (skips 
 
 
 class _PlanCache(dict):
-    """Plans keyed by shape tuples; optionally mirrored to a JSON file."""
+    """Plans keyed by shape tuples; optionally mirrored to a JSON file (``ops.configure(conv_plan_file=...)`` merges that file in)."""
 
     def __init__(self):
         super().__init__()
+        self.load()
+
+    def load(self):
         if _PLAN_FILE and os.path.exists(_PLAN_FILE):
             import json
 
@@ -683,9 +700,9 @@ def _conv1x1_x3(x, pc, residual=None, out=None, out_split=False, cfg=None, recor
     xs = x if isinstance(x, SplitRows) else split_rows(x)
     N, H, W, Cin = xs.shape
     M, Cout, dev = N * H * W, pc.cout, xs.device
+    if out_split and Cout % 32:
+        out_split = False                    # split rows come in groups of 32 channels: such a layer writes plain fp32
     if out_split:
-        if Cout % 32:
-            raise _lib.ArsegError("out_split needs Cout % 32 == 0")
         out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
     elif out is None:
         out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
@@ -703,12 +720,20 @@ def _conv1x1_x3(x, pc, residual=None, out=None, out_split=False, cfg=None, recor
         key = ("x3", dev.index, M, Cin, Cout, bool(out_split), residual is not None)
         cfg = _conv_plans.get(key)
         if cfg is None:
-            best_t = float("inf")
-            for c in range(7):
-                t = _time(lambda: run(c, False))
-                if t < best_t:
-                    cfg, best_t = c, t
-            _conv_plans[key] = cfg
+            if not _AUTOTUNE or torch.cuda.is_current_stream_capturing():
+                cfg = 0                      # no timing loop inside a graph capture / with the tuner off: the 128 x 128 tile (not cached)
+            else:
+                best_t = float("inf")
+                for c in range(7):
+                    try:
+                        t = _time(lambda: run(c, False))
+                    except _lib.ArsegError:  # a tile shape this problem does not admit
+                        continue
+                    if t < best_t:
+                        cfg, best_t = c, t
+                if cfg is None:
+                    raise _lib.ArsegError(f"gemm_x3: no tile configuration accepts M={M} K={Cin} N={Cout}")
+                _conv_plans[key] = cfg
     run(cfg, record)
     return SplitRows(out) if out_split else out
 
@@ -1182,6 +1207,17 @@ def psp_pool_matrix(x: torch.Tensor, sizes) -> torch.Tensor:
 _psp_interp = {}
 
 
+def psp_x3_foldable(pc) -> bool:
+    """psp_bottleneck_x3 pre-divides the pyramid terms by the epilogue's per-channel scale: a channel whose folded scale is 0 (pruned /
+    zero-initialised gamma) or tiny would give inf / overflow the split range, so such a module stays on the prior-sum + residual path.
+    Decided once per packed conv (one host read at the first forward), cached."""
+    ok = pc.__dict__.get("_x3_foldable")
+    if ok is None:
+        sc = pc.scale_h3.detach().abs()
+        ok = pc.__dict__["_x3_foldable"] = bool(torch.isfinite(sc).all().item()) and float(sc.min().item()) > 1e-4 * max(float(sc.max().item()), 1e-30)
+    return ok
+
+
 def psp_bottleneck_x3(feats: torch.Tensor, t: torch.Tensor, pc, sizes, out_split: bool = True):
     """PSPModule's folded bottleneck (model/pspnet.py:14-31) as ONE GEMM:  relu(W_f f + b + sum_s upsample(t_s))  with the pyramid sum written as
     B . T -- B [H*W, 64] the bilinear interpolation matrix of the pooled rows (built once per shape by running psp_prior_sum on an identity, so it
@@ -1200,9 +1236,10 @@ def psp_bottleneck_x3(feats: torch.Tensor, t: torch.Tensor, pc, sizes, out_split
     fac = pc.__dict__.get("_x3_unscale")
     if fac is None:
         fac = pc.__dict__["_x3_unscale"] = (1.0 / pc.scale_h3).contiguous()          # the epilogue multiplies the accumulator by scale_h3
-    w2 = torch.zeros((N, Cout, 1, 64), dtype=torch.float32, device=dev)
-    w2[:, :, 0, :rows] = (t.reshape(N, rows, Cout) * fac).transpose(1, 2)
-    w2s = split_rows(w2)
+        # (a channel whose folded scale is 0 or tiny cannot be un-scaled: psp_x3_foldable() keeps such a module on the residual path)
+    # the per-image pyramid operand [N, Cout, 64] as split rows, straight from t (no torch arithmetic inside the step)
+    w2s = SplitRows(torch.empty((N, Cout, 1, 64), dtype=torch.float32, device=dev))
+    _launch("psp_w2_split", lib.arseg_psp_w2_split_fwd, _ptr(t.contiguous()), _ptr(fac), _ptr(w2s.t), N, rows, Cout, _stream())
     xs = split_rows(feats)
     out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
     rw = _range_word(dev) if (out_split and _RANGE_MODE == "device") else None
@@ -1401,7 +1438,10 @@ def argmax_confusion(logits: torch.Tensor, label: Optional[torch.Tensor], H: int
 
 def _apply_config():
     """Push ``ops.config`` into the module-level switches the hot paths read."""
-    global _AUTOTUNE, _math, _RANGE_MODE, _RANGE_GUARD, _NATIVE_FIND, _WINOGRAD, _UP2_TAPS
+    global _AUTOTUNE, _math, _RANGE_MODE, _RANGE_GUARD, _NATIVE_FIND, _WINOGRAD, _UP2_TAPS, _PLAN_FILE
+    if config.conv_plan_file != _PLAN_FILE:          # a new plan file: its plans join the cache, later plans are mirrored to it
+        _PLAN_FILE = config.conv_plan_file
+        _conv_plans.load()
     _AUTOTUNE, _math = config.conv_autotune, _MATH_NAMES[config.conv_math]
     _RANGE_MODE = config.conv_range_guard if config.conv_range_guard in ("device", "host", "off") else "device"
     _RANGE_GUARD = _RANGE_MODE == "host"

@@ -252,6 +252,10 @@ int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bia
                             int out_ld, int N, int H, int W, int Cout, int dil, int act, float prelu_slope, float m_scale,
                             arseg_stream_t stream);
 
+/* The per-image pyramid operand of arseg_gemm_x3_cat_fwd for the folded PSP bottleneck (model/pspnet.py:14-31) in one pass:
+ * out[n][co][k] (split rows, K = 64) = t[n][k][co] * unscale[co] for k < rows, 0 beyond.  t fp32 [N, rows, Cout], rows <= 64. */
+int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, arseg_stream_t stream);
+
 /* (Part of the nn.Conv2d replacement above: the GEMM inside conv3x3 on the Winograd route, /root/reference/model/extractors.py:30-32,
  * the 1x1 bottleneck of PSPModule, model/pspnet.py:26, and the low-resolution tap GEMM of PSPUpsample, model/pspnet.py:38-46.)
  * Batched GEMM on operands that are already split into fp16 (hi, lo) pairs ("split rows": a row of K values, K % 32 == 0, is K/32

@@ -100,3 +100,60 @@ def test_multi_rank_gloo_matches_single_process(world, mode):
     assert set(merged) == set(single)
     for k in single:
         assert torch.equal(torch.from_numpy(merged[k]), single[k])
+
+
+def _range_worker(rank, world, port, q):
+    """Rank 0's pass trips the operand-range word, rank 1's does not: both must repeat (same collectives on every rank) and the histogram
+    is reduced once, from the final pass."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops
+
+    state = {"math": "f16x3", "runs": 0, "resets": 0}
+    ops.range_tripped = lambda: state["math"] == "f16x3" and rank == 0 and state["runs"] > 0
+
+    def set_math(name):
+        prev, state["math"] = state["math"], name
+        return prev
+
+    ops.set_conv_math = set_math
+
+    def run():
+        state["runs"] += 1
+        h = torch.zeros(3, 3, dtype=torch.int64)
+        h[rank, rank] = 10 * state["runs"] + (1 if state["math"] == "f32" else 0)      # the pass and its arithmetic are visible in the result
+        h[rank, 2] = state["runs"]
+        h[2, 2] = 5
+        return h
+
+    def reset():
+        state["resets"] += 1
+
+    miou = ev._range_safe(run, [1, 2, 3], 3, reset)
+    q.put((rank, state["runs"], state["resets"], state["math"], miou))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_range_fallback_is_collective():
+    """the decision to repeat an evaluation pass on the fp32 back end is taken by all ranks together."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_range_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, runs, resets, math, miou in results:
+        assert runs == 2 and resets == 1 and math == "f16x3"            # both ranks repeated once, counters reset, back end restored
+    # the histogram that is reduced is the sum of the SECOND passes only
+    from arseg_amd import evaluation as ev
+    want = ev._miou(torch.tensor([[21, 0, 2], [0, 21, 2], [0, 0, 10]]), 3)
+    assert results[0][4] == results[1][4] == want
