@@ -35,6 +35,9 @@
 #ifndef ROLL_LRTAB
 #define ROLL_LRTAB 0          // 1: the row taps of the lr_up rows come from a table the tap wave writes (measured slower: an LDS round trip in
 #endif                        // front of the lr loads, and the tap wave is the longest of H2)
+#ifndef ROLL_SPLIT6
+#define ROLL_SPLIT6 1
+#endif
 #ifndef ROLL_CPRIO
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
 #endif
@@ -94,9 +97,21 @@ struct RollParams {
     unsigned long long *dbg;
 };
 
+// fp32 -> two fp16 (x = hi + lo, 22 bits together; see arseg_split_f16) in 6 instructions per 4 values: the lo halves are written by
+// v_fma_mixlo / mixhi_f16 straight into their packed register (arseg_split_f16: fp32 differences + a packing convert, 8 instructions).
+// The lo half is rounded to nearest instead of toward zero; beyond |x| = 131008 it becomes Inf instead of clamping -- far outside the
+// features this kernel sees (the tile kernel measured this form 2 % slower; here the VALU issue count is what bounds a half step).
 __device__ __forceinline__ void split4(const f32x4 v, u32x2 &hi, u32x2 &lo) {
+#if ROLL_SPLIT6
+    unsigned h01, h23, l01, l23;
+    asm("v_cvt_pkrtz_f16_f32 %0, %4, %5\n\tv_cvt_pkrtz_f16_f32 %1, %6, %7\n\t"
+        "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23) : "v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
     unsigned h01, h23, l01, l23;
     arseg_split_f16(v, h01, h23, l01, l23);
+#endif
     hi = u32x2{h01, h23}; lo = u32x2{l01, l23};
 }
 __device__ __forceinline__ u32x4 split4r(const f32x4 v) {      // the record form {4 hi | 4 lo}
