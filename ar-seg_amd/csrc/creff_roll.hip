@@ -36,7 +36,7 @@
 #define ROLL_LRTAB 0          // 1: the row taps of the lr_up rows come from a table the tap wave writes (measured slower: an LDS round trip in
 #endif                        // front of the lr loads, and the tap wave is the longest of H2)
 #ifndef ROLL_SPLIT6
-#define ROLL_SPLIT6 1
+#define ROLL_SPLIT6 0          // 1: lo halves by v_fma_mixlo / mixhi_f16 (6 instead of 8 instructions per 4 values): measured 2 % SLOWER (5685 vs 5572 cycles per step)
 #endif
 #ifndef ROLL_CPRIO
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
