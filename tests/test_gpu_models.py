@@ -540,7 +540,7 @@ def _nccl_worker(rank, world, port, q, mode):
         hist = torch.tensor([float(out.shape[0])], device=dev)
         dist.all_reduce(hist)                                        # the confusion-matrix reduction (evaluation.py:134-135) on RCCL
     torch.cuda.synchronize()
-    q.put((rank, list(runner.plan), out.cpu(), float(hist)))
+    q.put((rank, list(runner.plan), out.cpu().numpy().copy(), float(hist)))      # by value: a shared-memory handle dies with the worker
     dist.barrier()
     dist.destroy_process_group()
 
@@ -590,5 +590,100 @@ def test_two_rank_rccl_matches_single_process(dev, mode):
             with torch.no_grad():
                 ref = ops.to_nhwc(hr(torch.from_numpy(clip["frames"][0:1]).to(dev))[-1])
                 want, _ = ev.alter_res_step_fast(lr, ref, torch.from_numpy(clip["frames"][d:d + 1]).to(dev), torch.from_numpy(clip["mv"][d:d + 1]).to(dev), 0.5)
-            assert torch.equal(out[i:i + 1], want.cpu()), (rank, g, d)
+            assert np.array_equal(out[i:i + 1], want.cpu().numpy()), (rank, g, d)
     assert total == n_gops * 11
+
+
+def _gloo_shared_gpu_worker(rank, world, port, q, mode):
+    """One of `world` processes that share cuda:0 and exchange the keyframe features over gloo: the HIP path + the exchange buffers + the
+    side-stream ordering of GopRunner.run_overlapped together, without a second GPU."""
+    import os as _os
+
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.gop import GopRunner
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ops.configure(conv_autotune=False)          # the same launch plans in every process: the comparison is bit for bit
+    H, W = 64, 96
+    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+    n_gops = 1 if mode == "single" else world
+    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12)
+    clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
+    keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
+    fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner.plan]).to(dev)
+    mb = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in runner.plan]).to(dev)
+    like = torch.empty((H, W, 64), dtype=torch.float32, device=dev)
+    outs = []
+    with torch.no_grad():
+        for _ in range(2):                      # twice on one lane: the second step reuses the lane's exchange buffer and side stream
+            outs.append(runner.run_overlapped(keyframes, fb, mb, lambda f: ev.alter_res_phase1(lr, f, 0.5),
+                                              lambda feat, refs, mvq: ev.alter_res_phase2(lr, feat, refs, mvq), like=like))
+    torch.cuda.synchronize()
+    q.put((rank, list(runner.plan), outs[0].cpu().numpy().copy(), outs[1].cpu().numpy().copy()))      # by value: a shared-memory handle dies with the worker
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["batched", "single"])
+def test_two_ranks_on_one_gpu_gloo_match_single_process(dev, mode):
+    """GopRunner.run_overlapped on the HIP path with the exchange over gloo, two processes sharing ONE GPU -- each rank's
+    outputs equal, bit for bit, what a single process computes for the same frames (same batch, same launch plans).  Covers what the
+    CPU gloo tests (toy functions) and the skipped RCCL test leave out on a 1-GPU box: exchange buffers, side stream, stream joins."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.gop import frame_plan
+    from arseg_amd.model import PSPNet, PSPNetWithFuse
+
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gloo_shared_gpu_worker, args=(r, world, port, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    prev = ops.configure(conv_autotune=False)
+    try:
+        H, W = 64, 96
+        hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+        lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+        synth.load_synth_weights(hr, 0)
+        synth.load_synth_weights(lr, 1)
+        hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+        n_gops = 1 if mode == "single" else world
+        clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
+        plans = frame_plan(n_gops, 12, world)
+        seen = set()
+        with torch.no_grad():
+            refs = {g: ops.to_nhwc(hr(torch.from_numpy(clips[g]["frames"][0:1]).to(dev))[-1])[0] for g in range(n_gops)}
+            for rank, plan, out0, out1 in results:
+                assert plan == plans[rank]
+                fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in plan]).to(dev)
+                mb = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in plan]).to(dev)
+                want = ev.alter_res_phase2(lr, ev.alter_res_phase1(lr, fb, 0.5), [refs[g] for g, _ in plan], mb).cpu()
+                assert np.array_equal(out0, want.numpy()) and np.array_equal(out1, want.numpy()), rank
+                seen.update(plan)
+        assert len(seen) == n_gops * 11
+    finally:
+        ops.configure(**prev)
