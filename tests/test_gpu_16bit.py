@@ -202,13 +202,13 @@ def test_bisenet16_golden(dev, golden, manifest, dtype):
     with torch.no_grad():
         out, o16, o32, fuse = hr(t(g["x"]).to(dev))
     assert out.dtype == torch.float32 and fuse.dtype == dtype and out.shape == g["out"].shape and fuse.shape == g["feat_fuse"].shape
-    rel = {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]            # measured 4e-3 / 3e-2 (x ~4 margin)
+    rel = {torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]              # measured <= 1.5e-3 / 1.2e-2 of the tensor's magnitude (x 2.5 margin)
     scale_f, scale_o = float(np.abs(g["feat_fuse"]).max()), float(np.abs(g["out"]).max())
     e_f, e_o = maxdiff(fuse.float(), g["feat_fuse"]), maxdiff(out, g["out"])
     agree = float((out.argmax(1).cpu().numpy() == g["out"].argmax(1)).mean())
     print(f"\\n[{dtype}] BiSeNetV1: feat_fuse err {e_f:.3e} (max {scale_f:.1f}), logits err {e_o:.3e} (max {scale_o:.1f}), labels equal {agree:.4f}")
     assert e_f <= rel * scale_f and e_o <= rel * scale_o
-    assert agree >= {torch.float16: 0.99, torch.bfloat16: 0.93}[dtype]
+    assert agree >= {torch.float16: 0.998, torch.bfloat16: 0.99}[dtype]      # measured 0.9996-0.9998 / 0.9960-0.9976
     g2 = golden("g6_bisefuse")
     lr = _bise16(manifest, dev, True, dtype)
     with torch.no_grad():
@@ -237,8 +237,8 @@ def test_alter_res16_golden(dev, golden, manifest, dtype):
     e = maxdiff(out, g["out"])
     agree = float((pred.cpu().long().numpy() == g["preds"]).mean())
     print(f"\\n[{dtype}] EvalAlterRes step: logits err {e:.3e} (max {float(np.abs(g['out']).max()):.1f}), labels equal {agree:.4f}")
-    assert e <= {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype] * float(np.abs(g["out"]).max())
-    assert agree >= {torch.float16: 0.99, torch.bfloat16: 0.93}[dtype]
+    assert e <= {torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype] * float(np.abs(g["out"]).max())
+    assert agree >= {torch.float16: 0.998, torch.bfloat16: 0.99}[dtype]      # measured 0.9996-0.9998 / 0.9960-0.9976
     assert int(hist.sum()) == int((label != 255).sum())
 
 
@@ -247,7 +247,7 @@ def test_bisenet16_odd_sizes_golden(dev, golden, manifest, dtype):
     """The odd-size path of BASELINE configs[4] (0.3x: 307x614 -> 40x78 maps; here the reference's 67x131 fixture G6-odd, whose
     16/32-stride maps need the re-interpolation branches of bisenet.py:298) with 16-bit storage, HR branch and LR phase 1."""
     go = golden("g6_biseodd")
-    rel = {torch.float16: 1.5e-2, torch.bfloat16: 1.2e-1}[dtype]
+    rel = {torch.float16: 4e-3, torch.bfloat16: 3e-2}[dtype]
     hr, lr = _bise16(manifest, dev, False, dtype), _bise16(manifest, dev, True, dtype)
     with torch.no_grad():
         oo, _, _, fo = hr(t(go["x"]).to(dev))
