@@ -189,6 +189,21 @@ __device__ __forceinline__ void stencil2r(const f32x4 (&w)[10], const f32x4 (&r0
     oa = a; ob = b;
 }
 
+// half and half: taps 0..4 in registers (requested before the barrier), taps 5..8 + bias from LDS -- the first taps read only the window rows
+// the lane holds, so the stencil starts without waiting for anything it requested in this half step
+__device__ __forceinline__ void stencil2h(const f32x4 (&wa)[5], const f32x4 *w, const f32x4 (&r0)[3], const f32x4 (&r1)[3], const f32x4 (&r2)[3],
+                                          const f32x4 (&r3)[3], f32x4 &oa, f32x4 &ob) {
+    f32x4 a = w[9], b = a;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { a = fma4(wa[j], r0[j], a); b = fma4(wa[j], r1[j], b); }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { a = fma4(wa[3 + j], r1[j], a); b = fma4(wa[3 + j], r2[j], b); }
+    { const f32x4 wj = w[5]; a = fma4(wj, r1[2], a); b = fma4(wj, r2[2], b); }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { const f32x4 wj = w[6 + j]; a = fma4(wj, r2[j], a); b = fma4(wj, r3[j], b); }
+    oa = a; ob = b;
+}
+
 #ifdef ROLL_TIMING
 // dev builds only: every wave accumulates the shader-clock ticks of its four segments per iteration (H1 work, wait at barrier A, H2 work,
 // wait at barrier B) and adds them to dbg[8 * wave + i] when it is done (tools/time_roll.py)
@@ -618,6 +633,11 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
 #pragma unroll
                 for (int j = 0; j < 10; ++j) wreg[j] = sm.Wd[kcg * 10 + j];
             }
+            f32x4 wqa[5];
+            if (ROLE == ROLE_Q) {
+#pragma unroll
+                for (int j = 0; j < 5; ++j) wqa[j] = sm.Wd[320 + qcg * 10 + j];
+            }
             RT(0);
             wg_sync();
             RT(1);
@@ -655,7 +675,7 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     for (int j = 0; j < 3; ++j) { m0[j] = sm.Ls[qcg * LPL + qx + j]; m1[j] = sm.Ls[(16 + qcg) * LPL + qx + j]; }
                     if (t >= 4) {
                         f32x4 a, b;
-                        stencil2(sm.Wd + 320 + qcg * 10, row[0], row[1], m0, m1, a, b);
+                        stencil2h(wqa, sm.Wd + 320 + qcg * 10, row[0], row[1], m0, m1, a, b);
                         u32x4 *dst = sm.Qr + (((qx >> 3) * 4 + (qcg >> 2)) * 4 + (qcg & 3)) * 16 + (qx & 7);
                         dst[0] = split4r(a); dst[8] = split4r(b);
                         savA = row[1][1];
