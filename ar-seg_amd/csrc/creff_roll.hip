@@ -540,6 +540,11 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
 
         for (int t = T_FIRST; t <= S + 5; ++t) {
             // ================================================================ H1
+            f32x4 gv[4];
+            if (ROLE == ROLE_KV) {      // two of the four gather taps travel under the value conv (all four: 16 more registers than the conv leaves)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, go[k] + 16u * gcg, 0, 0));
+            }
             if (ROLE == ROLE_KV) {
                 // ---- value records of rows rho = 2k, 2k + 1 (k = t - 2) from the four warp rows the key conv of H2(t-1) used (weights requested at
                 // the end of H2(t-1)); then the window moves on
@@ -564,14 +569,13 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
             // ---- gather t: the four taps of this lane's pixel (tap offsets read in H1(t-1); the lines were touched by the tap wave in H2(t-2),
             // so these come from the L2: no load of a compute wave is in flight across a barrier -- hipcc's s_waitcnt bookkeeping otherwise
             // makes the LDS reads of H2 wait for them)
-            f32x4 gv[4];
 #ifdef ROLL_NOGATHER
             const bool g_on = false;
 #else
             const bool g_on = t >= 0 && t <= S + 3;
 #endif
 #pragma unroll
-            for (int k = 0; k < 4; ++k)      // (outside [0, S+3] the offsets are stale but valid: the values are not used)
+            for (int k = ROLE == ROLE_KV ? 2 : 0; k < 4; ++k)      // (outside [0, S+3] the offsets are stale but valid: the values are not used)
                 gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, go[k] + 16u * gcg, 0, 0));
             // ---- lr_up rows ys + 2t - 7, ys + 2t - 6 (+1 halo column each side): the bilinear taps (lines touched by wave 12 in H2(t-2))
 #ifdef ROLL_NOLR
