@@ -38,6 +38,9 @@
 #ifndef ROLL_SPLIT6
 #define ROLL_SPLIT6 0          // 1: lo halves by v_fma_mixlo / mixhi_f16 (6 instead of 8 instructions per 4 values): measured 2 % SLOWER (5685 vs 5572 cycles per step)
 #endif
+#ifndef ROLL_LPRIO
+#define ROLL_LPRIO 0           // 1: raised issue priority while a producer wave requests its taps (and, for key/value waves, runs the value conv):
+#endif                         // zero-sum -- the producers' H1 drops 2600 -> 1900 cycles, the merge waves' rises 2380 -> 3280: a SIMD's H1 is issue-bound
 #ifndef ROLL_CPRIO
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
 #endif
@@ -541,6 +544,9 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         for (int t = T_FIRST; t <= S + 5; ++t) {
             // ================================================================ H1
             f32x4 gv[4];
+#if ROLL_LPRIO
+            __builtin_amdgcn_s_setprio(3);      // every wave's requests leave before anybody's arithmetic (the youngest waves of a SIMD otherwise issue theirs last)
+#endif
             if (ROLE == ROLE_KV) {      // two of the four gather taps travel under the value conv (all four: 16 more registers than the conv leaves)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) gv[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, go[k] + 16u * gcg, 0, 0));
@@ -607,6 +613,9 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     lv[i][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(lr_rsrc, r1 + lx1[i], 0, 0));
                 }
             }
+#if ROLL_LPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             // ---- sampling position of gather t + 2 (warp rows ys - 4 + 2(t+2), +1), fp64 like the reference; the MV was requested in H2(t-1)
             if (ROLE == ROLE_AUX && tap_lane && t >= -2 && t <= S + 1) {
                 const int gy = ys + 2 * t + trr, gx = x0 - 4 + tcc;
