@@ -51,7 +51,7 @@ PROTOTYPES = {
     "arseg_creff_fwd": (c_int, [_P] * 8 + [_P, _P, _P, c_int, _P, c_int] + [c_int] * 8 + [_STREAM]),
     "arseg_creff_fwd_ex": (c_int, [_P] * 8 + [_P, _P, _P, c_int, _P, c_int] + [c_int] * 10 + [_STREAM]),
     "arseg_creff_warp_fwd": (c_int, [_P, _P, c_int, c_int, _P] + [_P] * 6 + [_P, c_int, _P, _P, c_int, _P, c_int] + [c_int] * 8 + [_STREAM]),
-    "arseg_creff_warp_fwd_ex": (c_int, [_P, _P, c_int, c_int, _P] + [_P] * 6 + [_P, c_int, _P, _P, c_int, _P, c_int] + [c_int] * 10 + [_STREAM]),
+    "arseg_creff_warp_fwd_ex": (c_int, [_P, _P, c_int, c_int, _P] + [_P] * 6 + [_P, c_int, _P, _P, c_int, _P, c_int] + [c_int] * 11 + [_STREAM]),
     "arseg_to_c8_fwd": (c_int, [_P, c_int, c_int, _P, c_int, c_int, c_int, _STREAM]),
     "arseg_from_c8_fwd": (c_int, [_P, _P, c_int, c_int, c_int, c_int, c_int, _STREAM]),
     "arseg_conv_out_hw": (c_int, [POINTER(ConvDesc), POINTER(c_int), POINTER(c_int)]),

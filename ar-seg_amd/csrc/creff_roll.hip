@@ -817,12 +817,13 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
 }
 
 template <int NB>
-int launch(const RollParams &p, hipStream_t st) {
+int launch(const RollParams &p, int max_wgs, hipStream_t st) {
     static ArsegSmemAttr attr;
     if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(creff_roll_kernel<NB>), SMEM_BYTES)) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const long long nunits = (long long)p.nstrips * p.nseg * p.N;
+    if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;      // leave compute units to the kernels of other streams (the workgroups are persistent)
     const int grid = (int)(nunits < cus ? nunits : cus);
     hipLaunchKernelGGL((creff_roll_kernel<NB>), dim3(grid), dim3(NT), SMEM_BYTES, st, p);
     return arseg_launch_status();
@@ -841,7 +842,7 @@ extern "C" void arseg__roll_set_dbg(void *ptr) { g_roll_dbg = (unsigned long lon
 int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr, const float *wq,
                             const float *bq, const float *wk, const float *bk, const float *wv, const float *bv, float *p_out,
                             int p_layout, const float *wf, const float *bf, int n_cls, float *logits, int log_softmax, int N, int Hp,
-                            int Wp, int hp, int wp, int seg_rows, hipStream_t st) {
+                            int Wp, int hp, int wp, int seg_rows, int max_wgs, hipStream_t st) {
     const bool head = logits != nullptr;
     RollParams p;
     for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
@@ -862,6 +863,6 @@ int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv
 #ifdef ROLL_TIMING
     p.dbg = g_roll_dbg;
 #endif
-    if (!head) return launch<0>(p, st);
-    return n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
+    if (!head) return launch<0>(p, max_wgs, st);
+    return n_cls <= 16 ? launch<1>(p, max_wgs, st) : launch<2>(p, max_wgs, st);
 }

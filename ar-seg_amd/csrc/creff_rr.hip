@@ -773,7 +773,7 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
                                        const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
                                        const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
                                        float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
-                                       int impl, int seg_rows, arseg_stream_t stream) {
+                                       int impl, int seg_rows, int max_wgs, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(ref_nhwc_host); ARSEG_CHECK_PTR(mv_q); ARSEG_CHECK_PTR(lr); ARSEG_CHECK_PTR(wq); ARSEG_CHECK_PTR(bq); ARSEG_CHECK_PTR(wk);
     ARSEG_CHECK_PTR(bk); ARSEG_CHECK_PTR(wv); ARSEG_CHECK_PTR(bv); ARSEG_CHECK_PTR(p_out);
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(C); ARSEG_CHECK_POS(Hp); ARSEG_CHECK_POS(Wp); ARSEG_CHECK_POS(hp); ARSEG_CHECK_POS(wp);
@@ -793,13 +793,13 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
         if (!ARSEG_ALIGNED16(wf)) return ARSEG_EINVAL;
     }
     if (impl != ARSEG_CREFF_WARP_AUTO && impl != ARSEG_CREFF_WARP_TILES && impl != ARSEG_CREFF_WARP_ROLL) return ARSEG_EINVAL;
-    if (seg_rows < 0) return ARSEG_EINVAL;
+    if (seg_rows < 0 || max_wgs < 0) return ARSEG_EINVAL;
     for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
     // the rolling kernel (creff_roll.hip) is the default; with more than 16 classes its head spills registers: the tile kernel then
     if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16)))
         return arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
-                                       log_softmax, N, Hp, Wp, hp, wp, seg_rows, arseg_stream(stream));
+                                       log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, arseg_stream(stream));
     RRParams p;
     for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
     for (int i = N; i < MAXN; ++i) p.ref[i] = nullptr;
@@ -825,5 +825,5 @@ extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int
                                     float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
                                     arseg_stream_t stream) {
     return arseg_creff_warp_fwd_ex(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits, log_softmax,
-                                   N, C, Hp, Wp, hp, wp, kH, kW, ARSEG_CREFF_WARP_AUTO, 0, stream);
+                                   N, C, Hp, Wp, hp, wp, kH, kW, ARSEG_CREFF_WARP_AUTO, 0, 0, stream);
 }

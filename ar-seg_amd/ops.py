@@ -47,6 +47,7 @@ class Config:
     creff_warp_impl  [ARSEG_CREFF_WARP_IMPL = roll | tiles]     fused warp + CReFF kernel for C = 64: the rolling kernel (csrc/creff_roll.hip, default) or
                      the 16 x 16 tile kernel of rounds 2-3 (csrc/creff_rr.hip)
     creff_seg_rows   [ARSEG_CREFF_SEG_ROWS = n]                 rows of a strip segment of the rolling kernel (0: the library's default)
+    creff_max_wgs    [ARSEG_CREFF_MAX_WGS = n]                  upper bound on the rolling kernel's persistent workgroups (0: one per compute unit)
     lr_subbatch      [ARSEG_LR_SUBBATCH = n]                    evaluate the LR batch of a GOP in slices of n frames (bounds the working set)
     (ARSEG_HIP_LIB = <path> selects an alternative library build; it is read by _lib before anything is loaded.)"""
     conv_math: str = "f16x3"
@@ -61,6 +62,7 @@ class Config:
     creff_tile_rows: int = 0
     creff_warp_impl: str = ""
     creff_seg_rows: int = 0
+    creff_max_wgs: int = 0
     lr_subbatch: int = 0
 
     @classmethod
@@ -71,7 +73,7 @@ class Config:
                    conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0", conv_gemm_x3={"0": False, "wino": "wino"}.get(e("ARSEG_CONV_GEMM_X3", "1"), True),
                    conv_range_guard={"1": "host", "host": "host", "0": "off", "off": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), "device"),
                    conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=int(e("ARSEG_CREFF_TY", "0") or 0),
-                   creff_warp_impl=e("ARSEG_CREFF_WARP_IMPL", ""), creff_seg_rows=int(e("ARSEG_CREFF_SEG_ROWS", "0") or 0),
+                   creff_warp_impl=e("ARSEG_CREFF_WARP_IMPL", ""), creff_seg_rows=int(e("ARSEG_CREFF_SEG_ROWS", "0") or 0), creff_max_wgs=int(e("ARSEG_CREFF_MAX_WGS", "0") or 0),
                    lr_subbatch=int(e("ARSEG_LR_SUBBATCH", "0") or 0))
 
 
@@ -513,7 +515,7 @@ def creff_warp(refs_nhwc, mv_q: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=
     impl = {"tiles": 1, "roll": 2}.get(config.creff_warp_impl, 0)
     _launch("creff_warp", _lib.load().arseg_creff_warp_fwd_ex, ptrs, _ptr(mv_q), H, W, _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq),
             _ptr(attn.wk), _ptr(attn.bk), _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), p_layout, _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
-            1 if log_softmax else 0, B, C, Hp, Wp, hp, wp, kH, kW, impl, max(0, int(config.creff_seg_rows)), _stream(),
+            1 if log_softmax else 0, B, C, Hp, Wp, hp, wp, kH, kW, impl, max(0, int(config.creff_seg_rows)), max(0, int(config.creff_max_wgs)), _stream(),
             flops=B * Hp * Wp * C * (250 + 2 * n_cls),
             nbytes=B * (4 * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp) + 4 * H * W))
     return p_out, logits

@@ -135,12 +135,13 @@ int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q,
 /* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_warp_impl -- AUTO / ROLL: the rolling
  * kernel (creff_roll.hip: a workgroup walks down a 16-column strip, key / value records of the 7 x 7 windows in LDS rings, producer and
  * consumer waves of different rows overlap); TILES: the 16 x 16 tile kernel of rounds 2-3 (creff_rr.hip).  seg_rows = rows of a strip
- * segment (the unit of work of the rolling kernel; 0 = default, rounded up to even).  No environment variables are read. */
+ * segment (the unit of work of the rolling kernel; 0 = default, rounded up to even); max_wgs = upper bound on its persistent
+ * workgroups (0 = one per compute unit; fewer leave compute units to kernels of other streams).  No environment variables are read. */
 int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
                             const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,
                             const float *bv, float *p_out, int p_layout, const float *wf, const float *bf, int n_cls,
                             float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
-                            int impl, int seg_rows, arseg_stream_t stream);
+                            int impl, int seg_rows, int max_wgs, arseg_stream_t stream);
 
 /* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_impl (AUTO: the matrix-core kernel
  * for C >= 128, the VALU kernel otherwise); mfma_tile_rows = 0 (by launch size), 8 or 16.  No environment variables are read. */
