@@ -995,9 +995,11 @@ def test_creff_warp_wide_and_16bit(dev, C, Hp, Wp, hp, wp, H, W, n_cls, logsm, l
     (7, 9, 7, 9, 0, False, "nhwc"),         # image smaller than a tile, same-size lr, no head
     (64, 96, 32, 48, 12, True, "c8"),       # several tiles in both directions
 ])
-def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout):
-    """arseg_creff_warp_fwd (MV warp fused into the CReFF tile staging) against the oracle's warp -> MyAttention -> head and,
-    bit for the warp / tolerance for the rest, against the two-kernel path (arseg_warp_mvq_fwd + arseg_creff_fwd)."""
+@pytest.mark.parametrize("impl,seg_rows,max_wgs", [("roll", 0, 0), ("tiles", 0, 0), ("roll", 6, 3)])
+def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout, impl, seg_rows, max_wgs):
+    """arseg_creff_warp_fwd_ex (MV warp fused into CReFF) against the oracle's warp -> MyAttention -> head: the rolling kernel
+    (csrc/creff_roll.hip, the default; also with 6-row strip segments on 3 persistent workgroups, so that every workgroup walks several
+    segments and every segment boundary lies inside the image) and the 16 x 16 tile kernel (csrc/creff_rr.hip)."""
     from arseg_amd import _lib, ops, synth
     from arseg_amd.model import MyAttention
     from arseg_amd.packing import PackedAttention
@@ -1023,7 +1025,11 @@ def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout):
             head = (wf.to(dev), bf.to(dev))
         refs_d = [r.permute(1, 2, 0).contiguous().to(dev) for r in refs]
         lay = _lib.C8 if layout == "c8" else _lib.NHWC
-        p, logits = ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, head, logsm, 7, 7, p_layout=lay)
+        prev = ops.configure(creff_warp_impl=impl, creff_seg_rows=seg_rows, creff_max_wgs=max_wgs)
+        try:
+            p, logits = ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, head, logsm, 7, 7, p_layout=lay)
+        finally:
+            ops.configure(**prev)
         got = ops.from_c8(p, _lib.NCHW) if layout == "c8" else p.permute(0, 3, 1, 2)
         tol = 1e-4 if gain < 1 else 3e-4
         assert maxdiff(got, want) <= tol
