@@ -697,6 +697,15 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     for (int j = 0; j < 3; ++j) { row[0][j] = m0[j]; row[1][j] = m1[j]; }
                 }
             } else {
+                // ---- motion vectors of gather t + 3 (identity-resize case: one int16 pair per pixel).  FIRST: behind the touch loads below,
+                // hipcc puts an s_waitcnt vmcnt(0) in front of this request (registers of loads it cannot prove finished) and the wave --
+                // the longest of H2 -- sits out the HBM latency of the lines it has just touched
+                if (tap_lane && mv_ident && t <= S) {
+                    const int gy = ys + 2 * t + 2 + trr, gx = x0 - 4 + tcc;
+                    mvv = 0u;
+                    if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp)
+                        mvv = *reinterpret_cast<const unsigned *>(p.mv + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * 2);
+                }
                 // ---- tap table of gather t + 2 from the sampling positions of H1(t)
                 if (tap_lane && t >= -2 && t <= S + 1) {
                     const int gy = ys + 2 * t + trr, gx = x0 - 4 + tcc;
@@ -723,13 +732,6 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     l = fminf(fmaxf(l, 0.f), 1.f);
                     const float iny = (unsigned)gy < (unsigned)Hp ? 1.f : 0.f;
                     sm.LrRow[tl - NGP] = u32x4{(unsigned)(i0 * p.wp) * (CH * 4u), (unsigned)(i1 * p.wp) * (CH * 4u), __float_as_uint((1.f - l) * iny), __float_as_uint(l * iny)};
-                }
-                // ---- motion vectors of gather t + 3 (identity-resize case: one int16 pair per pixel)
-                if (tap_lane && mv_ident && t <= S) {
-                    const int gy = ys + 2 * t + 2 + trr, gx = x0 - 4 + tcc;
-                    mvv = 0u;
-                    if ((unsigned)gy < (unsigned)Hp && (unsigned)gx < (unsigned)Wp)
-                        mvv = *reinterpret_cast<const unsigned *>(p.mv + ((size_t)n * p.H * p.W + (size_t)gy * p.W + gx) * 2);
                 }
                 // ---- wave 12 touches the lr pixels under the lr_up rows of iteration t + 2 (rows ys + 2t - 3, ys + 2t - 2): lane = (lr row 0..3 from
                 // the first tap row, lr column 0..15 from the first tap column of the strip), both lines of the pixel
