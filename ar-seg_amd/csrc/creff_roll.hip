@@ -802,6 +802,14 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     sc.u_first = (int)((long long)nunits * xcd / nx) + slot;
     sc.u_last = (int)((long long)nunits * (xcd + 1) / nx);
 
+#ifdef ROLL_ONLY      // dev builds only: one role alone, to read ITS register count off -Rpass-analysis=kernel-resource-usage (0 / 1: consumers, 2: key/value, 3: aux, 4: query)
+    if (ROLL_ONLY == 0) consumer<NB, 0>(p, sm, sc, tid, wave);
+    if (ROLL_ONLY == 1) consumer<NB, 1>(p, sm, sc, tid, wave);
+    if (ROLL_ONLY == 2) producer<ROLE_KV>(p, sm, sc, tid, wave);
+    if (ROLL_ONLY == 3) producer<ROLE_AUX>(p, sm, sc, tid, wave);
+    if (ROLL_ONLY == 4) producer<ROLE_Q>(p, sm, sc, tid, wave);
+    return;
+#endif
     if (wave < NCONS) {
         __builtin_amdgcn_s_setprio(ROLL_CPRIO);       // the consumers are the critical path of both halves of an iteration
         if (wave < 2) consumer<NB, 0>(p, sm, sc, tid, wave);
