@@ -54,7 +54,7 @@ def main():
     d = dbg.cpu().numpy().reshape(nw, 8).astype(np.float64)
     res = {"launch_ms": s.elapsed_time(e), "waves": []}
     print("launch ms", s.elapsed_time(e))
-    print(f"{'wave':>4s} {'H1':>8s} {'waitA':>8s} {'H2':>8s} {'waitB':>8s} {'total':>8s}   ticks per step (100 MHz clock: x ~21 for shader cycles)")
+    print(f"{'wave':>4s} {'H1':>8s} {'waitA':>8s} {'H2':>8s} {'waitB':>8s} {'total':>8s}   s_memtime ticks per step (about 0.5 ns each: launch time / iterations)")
     for w in range(nw):
         n = d[w, 4]
         if n == 0:
