@@ -83,7 +83,8 @@ constexpr int LR_OFF = TO_OFF + NGP * 16;            //          [2] lr taps of 
 constexpr int WD_OFF = LR_OFF + 2 * 16;              //          depthwise weights [key | value | query][16 groups][9 taps + bias]
 constexpr int WF_OFF = WD_OFF + 3 * 160 * 16;        // 147,904  classifier records [4 chunks][4 groups][32] {4 hi | 4 lo}
 constexpr int BF_OFF = WF_OFF + 4 * 4 * 32 * 16;     // 156,096  classifier bias [32]
-constexpr int SMEM_BYTES = BF_OFF + 32 * 4;          // 156,224 <= 163,840
+constexpr int SC_OFF = BF_OFF + 32 * 4;              //          this workgroup's list of pieces (struct PieceTab)
+constexpr int SMEM_BYTES = SC_OFF + 16 + 64 * 16;    // 158,896 <= 163,840
 constexpr int T_FIRST = -3;                         // first iteration of a segment (MV request of gather 0); the last is S + 5
 constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -94,7 +95,7 @@ struct RollParams {
     const int16_t *mv;            // [N][H][W][2] quarter-pel
     const float *lr, *wq, *bq, *wk, *bk, *wv, *bv, *wf, *bf;
     float *p_out, *logits;
-    int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout, nstrips, nseg, seg_rows;
+    int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout, nstrips, nseg, seg_rows, balanced;
     unsigned p_bytes, l_bytes, lr_bytes, ref_bytes;
     float sy, sx;
     unsigned long long *dbg;
@@ -234,12 +235,46 @@ struct Smem {
     u32x4 *TapO, *LrRow;
     float *Bfs;
 };
-struct Sched { int per_img, u_first, u_last, u_step; };      // this workgroup's units: u_first, u_first + u_step, ... < u_last
+// This workgroup's pieces of work; a piece = `S` steps (row pairs) of one 16-column strip of one frame from row `ys` on, and costs S + 9
+// iterations (the rings fill and drain).  Thread 0 writes the list to LDS once (at most MAXPIECES entries {frame, strip, ys, S}); every
+// role walks it.
+//   seg_rows given: fixed segments -- units (frame, segment, strip); XCD x owns a contiguous run of them, its workgroups take neighbouring
+//   strips of one segment row at the same time.
+//   default: the strips of all frames, frame-major, are dealt to the XCDs in contiguous runs; the G workgroups of an XCD walk G neighbouring
+//   strips top to bottom at the same time (the halo columns neighbours share are fetched into that L2 once), as often as that goes, and
+//   the strips that are left are cut into G equal runs of steps -- every workgroup ends within one fill of every other.  (Fixed 128-row
+//   segments: 11 units x 73 iterations per workgroup for the 11-frame headline launch; this: 2 x 265 + 192 + 9 or 18 = 731 .. 740.)
+constexpr int MAXPIECES = 64;
+struct PieceTab { int count, pad[3]; int4 e[MAXPIECES]; };
+__device__ void build_pieces(const RollParams &p, PieceTab *tab) {      // (thread 0)
+    const int nx = min(8, (int)gridDim.x);
+    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
+    const int G = ((int)gridDim.x - xcd + nx - 1) / nx;      // workgroups of this XCD
+    const int T = p.nstrips * p.nseg * p.N, a = (int)((long long)T * xcd / nx), b = (int)((long long)T * (xcd + 1) / nx);
+    const int npass = p.balanced ? (b - a) / G : (a + slot < b ? (b - a - slot + G - 1) / G : 0);
+    int c = 0;
+    for (int k = 0; k < npass && c < MAXPIECES; ++k) {
+        const int lin = a + slot + k * G, per_img = p.nstrips * p.nseg, n = lin / per_img, rem = lin - n * per_img, seg = rem / p.nstrips;
+        const int ys = seg * p.seg_rows;
+        tab->e[c++] = int4{n, rem - seg * p.nstrips, ys, (min(p.seg_rows, p.Hp - ys) + 1) >> 1};
+    }
+    if (p.balanced) {                                         // (nseg == 1: a unit is a whole strip)
+        const int SH = (p.Hp + 1) >> 1, s_rem = a + npass * G, tot = (b - s_rem) * SH, rpw = (tot + G - 1) / G;
+        int cur = min(slot * rpw, tot);
+        const int lin1 = min((slot + 1) * rpw, tot);
+        while (cur < lin1 && c < MAXPIECES) {
+            const int sidx = cur / SH, y = cur - sidx * SH, lin = s_rem + sidx, S = min(SH - y, lin1 - cur), n = lin / p.nstrips;
+            tab->e[c++] = int4{n, lin - n * p.nstrips, 2 * y, S};
+            cur += S;
+        }
+    }
+    tab->count = c;
+}
 
 // ============================================================================================== consumer: wave (patch pc, key half KH)
 // KH 0: key blocks 0..2 (+ merge / epilogue of the previous step), KH 1: key blocks 3..6
 template <int NB, int KH>
-__device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, const Sched &sc, const int tid, const int wave) {
+__device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, const PieceTab *sc, const int tid, const int wave) {
     constexpr int NBA = NB > 0 ? NB : 1;
     constexpr int B0 = KH ? 3 : 0, NBK = KH ? 4 : 3;
     const int Hp = p.Hp, Wp = p.Wp;
@@ -269,11 +304,12 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
     const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
     RT_DECL;
-    for (int unit = sc.u_first; unit < sc.u_last; unit += sc.u_step) {
-        const int n = unit / sc.per_img, rem = unit - n * sc.per_img;
-        const int seg = rem / p.nstrips, strip = rem - seg * p.nstrips;
-        const int x0 = strip * SW, ys = seg * p.seg_rows;
-        const int S = (min(p.seg_rows, Hp - ys) + 1) >> 1;
+    const int npieces = __builtin_amdgcn_readfirstlane(sc->count);
+    for (int piece = 0; piece < npieces; ++piece) {
+        const int4 pe = sc->e[piece];      // (read by all lanes, the same entry: readfirstlane keeps it -- and the descriptors built from it -- scalar)
+        const int n = __builtin_amdgcn_readfirstlane(pe.x), strip = __builtin_amdgcn_readfirstlane(pe.y);
+        const int ys = __builtin_amdgcn_readfirstlane(pe.z), S = __builtin_amdgcn_readfirstlane(pe.w);
+        const int x0 = strip * SW;
         RT_STEPS(S);
         // Store offsets of this lane's query pixel, split into a per-lane part that is constant down the strip (voffset; OOB for lanes
         // whose column or class lies outside) and a wave-uniform part that moves with the step (soffset: scalar arithmetic only).
@@ -475,7 +511,7 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
 // blended and staged in H1(j)  ->  consumed by the convs in H2(j).
 enum { ROLE_KV = 0, ROLE_Q = 1, ROLE_AUX = 2 };
 template <int ROLE>
-__device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, const Sched &sc, const int tid, const int wave) {
+__device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, const PieceTab *sc, const int tid, const int wave) {
     const int Hp = p.Hp, Wp = p.Wp;
     const int pl = tid - 64 * NCONS;                   // 0 .. 767
     const int gpx = pl >> 4, gcg = pl & 15;            // gather unit: staged warp pixel (row gpx / 24, column gpx % 24), channel group
@@ -498,11 +534,12 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
     }
     RT_DECL;
 
-    for (int unit = sc.u_first; unit < sc.u_last; unit += sc.u_step) {
-        const int n = unit / sc.per_img, rem = unit - n * sc.per_img;
-        const int seg = rem / p.nstrips, strip = rem - seg * p.nstrips;
-        const int x0 = strip * SW, ys = seg * p.seg_rows;
-        const int S = (min(p.seg_rows, Hp - ys) + 1) >> 1;
+    const int npieces = __builtin_amdgcn_readfirstlane(sc->count);
+    for (int piece = 0; piece < npieces; ++piece) {
+        const int4 pe = sc->e[piece];      // (read by all lanes, the same entry: readfirstlane keeps it -- and the descriptors built from it -- scalar)
+        const int n = __builtin_amdgcn_readfirstlane(pe.x), strip = __builtin_amdgcn_readfirstlane(pe.y);
+        const int ys = __builtin_amdgcn_readfirstlane(pe.z), S = __builtin_amdgcn_readfirstlane(pe.w);
+        const int x0 = strip * SW;
         RT_STEPS(S);
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ref[n]), 0, (int)p.ref_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr), 0, (int)p.lr_bytes, 0x00020000);
@@ -791,16 +828,10 @@ __global__ __launch_bounds__(NT) void creff_roll_kernel(const RollParams p) {
     }
     __syncthreads();
 
-    // Persistent workgroups, XCD-aware order (as creff_rr.hip): XCD x owns a contiguous run of units, its workgroups take neighbouring
-    // strips of one segment row at the same time, so the halo columns they share are fetched into one L2 once.
-    Sched sc;
-    sc.per_img = p.nstrips * p.nseg;
-    const int nunits = sc.per_img * p.N;
-    const int nx = min(8, (int)gridDim.x);
-    const int xcd = blockIdx.x % nx, slot = blockIdx.x / nx;
-    sc.u_step = ((int)gridDim.x - xcd + nx - 1) / nx;
-    sc.u_first = (int)((long long)nunits * xcd / nx) + slot;
-    sc.u_last = (int)((long long)nunits * (xcd + 1) / nx);
+    // Persistent workgroups, XCD-aware order (as creff_rr.hip): this workgroup's list of pieces (struct PieceTab)
+    PieceTab *sc = reinterpret_cast<PieceTab *>(smem + SC_OFF);
+    if (tid == 0) build_pieces(p, sc);
+    __syncthreads();
 
 #ifdef ROLL_ONLY      // dev builds only: one role alone, to read ITS register count off -Rpass-analysis=kernel-resource-usage (0 / 1: consumers, 2: key/value, 3: aux, 4: query)
     if (ROLL_ONLY == 0) consumer<NB, 0>(p, sm, sc, tid, wave);
@@ -832,7 +863,8 @@ int launch(const RollParams &p, int max_wgs, hipStream_t st) {
     if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(creff_roll_kernel<NB>), SMEM_BYTES)) return e;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const long long nunits = (long long)p.nstrips * p.nseg * p.N;
+    // workgroups: one per CU; fewer when the launch is small -- mode 0: one per unit, mode 1: at least 16 steps each (a piece costs 9 iterations of fill)
+    const long long nunits = p.balanced ? ((long long)p.nstrips * p.N * ((p.Hp + 1) >> 1) + 15) / 16 : (long long)p.nstrips * p.nseg * p.N;
     if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;      // leave compute units to the kernels of other streams (the workgroups are persistent)
     const int grid = (int)(nunits < cus ? nunits : cus);
     hipLaunchKernelGGL((creff_roll_kernel<NB>), dim3(grid), dim3(NT), SMEM_BYTES, st, p);
@@ -862,8 +894,21 @@ int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv
     p.N = N; p.Hp = Hp; p.Wp = Wp; p.hp = hp; p.wp = wp; p.H = H; p.W = W; p.n_cls = head ? n_cls : 0; p.log_softmax = log_softmax;
     p.p_layout = p_layout;
     p.nstrips = arseg_cdiv(Wp, SW);
-    if (seg_rows <= 0) seg_rows = Hp >= 256 ? 128 : Hp;      // segments of a strip: enough units to fill 256 CUs evenly, few enough that the
-    seg_rows = (seg_rows + 1) & ~1;                           // 7 fill iterations of a segment stay small beside its rows / 2 steps
+    p.balanced = seg_rows <= 0;                               // default: strips dealt in balanced runs of steps (struct PieceTab); seg_rows > 0: fixed segments
+    if (seg_rows <= 0) seg_rows = Hp;
+    seg_rows = (seg_rows + 1) & ~1;
+    if (!p.balanced) {                                        // a workgroup's list holds MAXPIECES pieces: longer segments if the launch has more
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;
+        for (;;) {
+            const long long units = (long long)p.nstrips * arseg_cdiv(Hp, seg_rows) * N, wgs = units < cus ? units : cus;
+            // (an XCD's share of the units over its share of the workgroups, both rounded against us)
+            const long long nx = wgs < 8 ? wgs : 8, share = (units + nx - 1) / nx, g = wgs / nx;
+            if ((share + g - 1) / g <= MAXPIECES || seg_rows >= Hp) break;
+            seg_rows *= 2;
+        }
+    }
     p.seg_rows = seg_rows; p.nseg = arseg_cdiv(Hp, seg_rows);
     p.p_bytes = (unsigned)((size_t)N * CH * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)N * n_cls * Hp * Wp * sizeof(float)) : 0u;
     p.lr_bytes = (unsigned)((size_t)N * CH * hp * wp * sizeof(float));

@@ -46,7 +46,7 @@ class Config:
     creff_tile_rows  [ARSEG_CREFF_TY = 8 | 16]                  pin the tile height of the matrix-core CReFF kernel
     creff_warp_impl  [ARSEG_CREFF_WARP_IMPL = roll | tiles]     fused warp + CReFF kernel for C = 64: the rolling kernel (csrc/creff_roll.hip, default) or
                      the 16 x 16 tile kernel of rounds 2-3 (csrc/creff_rr.hip)
-    creff_seg_rows   [ARSEG_CREFF_SEG_ROWS = n]                 rows of a strip segment of the rolling kernel (0: the library's default)
+    creff_seg_rows   [ARSEG_CREFF_SEG_ROWS = n]                 fixed strip segments of n rows for the rolling kernel (0: its balanced default schedule)
     creff_max_wgs    [ARSEG_CREFF_MAX_WGS = n]                  upper bound on the rolling kernel's persistent workgroups (0: one per compute unit)
     lr_subbatch      [ARSEG_LR_SUBBATCH = n]                    evaluate the LR batch of a GOP in slices of n frames (bounds the working set)
     (ARSEG_HIP_LIB = <path> selects an alternative library build; it is read by _lib before anything is loaded.)"""

@@ -135,7 +135,8 @@ int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q,
 /* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_warp_impl -- AUTO / ROLL: the rolling
  * kernel (creff_roll.hip: a workgroup walks down a 16-column strip, key / value records of the 7 x 7 windows in LDS rings, producer and
  * consumer waves of different rows overlap); TILES: the 16 x 16 tile kernel of rounds 2-3 (creff_rr.hip).  seg_rows = rows of a strip
- * segment (the unit of work of the rolling kernel; 0 = default, rounded up to even); max_wgs = upper bound on its persistent
+ * segment (> 0: the rolling kernel works on fixed segments of that many rows, rounded up to even, and raised if a workgroup would get more
+ * than 64 of them; 0 = default: whole strips dealt to the workgroups, the remainder cut into equal runs of row pairs); max_wgs = upper bound on its persistent
  * workgroups (0 = one per compute unit; fewer leave compute units to kernels of other streams).  No environment variables are read. */
 int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
                             const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,

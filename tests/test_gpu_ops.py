@@ -995,7 +995,9 @@ def test_creff_warp_wide_and_16bit(dev, C, Hp, Wp, hp, wp, H, W, n_cls, logsm, l
     (7, 9, 7, 9, 0, False, "nhwc"),         # image smaller than a tile, same-size lr, no head
     (64, 96, 32, 48, 12, True, "c8"),       # several tiles in both directions
 ])
-@pytest.mark.parametrize("impl,seg_rows,max_wgs", [("roll", 0, 0), ("tiles", 0, 0), ("roll", 6, 3)])
+# ("roll", 0, 0): the rolling kernel with its default schedule (balanced runs of steps); ("roll", 6, 3): fixed 6-row segments on 3 workgroups
+# (many pieces each); ("roll", 0, 5) / ("roll", 0, 11): the balanced schedule on few workgroups -- whole-strip passes plus a remainder cut mid-strip
+@pytest.mark.parametrize("impl,seg_rows,max_wgs", [("roll", 0, 0), ("tiles", 0, 0), ("roll", 6, 3), ("roll", 0, 5), ("roll", 0, 11)])
 def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout, impl, seg_rows, max_wgs):
     """arseg_creff_warp_fwd_ex (MV warp fused into CReFF) against the oracle's warp -> MyAttention -> head: the rolling kernel
     (csrc/creff_roll.hip, the default; also with 6-row strip segments on 3 persistent workgroups, so that every workgroup walks several
