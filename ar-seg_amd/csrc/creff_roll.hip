@@ -918,6 +918,14 @@ int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv
 #ifdef ROLL_TIMING
     p.dbg = g_roll_dbg;
 #endif
+    if (p.balanced) {      // a workgroup's list of pieces must hold its whole-strip passes + the pieces of its remainder run
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+        if (max_wgs > 0 && max_wgs < cus) cus = max_wgs;
+        const long long T = (long long)p.nstrips * N, nunits = (T * ((Hp + 1) >> 1) + 15) / 16, wgs = nunits < cus ? nunits : cus;
+        const long long nx = wgs < 8 ? wgs : 8, share = (T + nx - 1) / nx, g = wgs / nx;
+        if (share / g + 3 > MAXPIECES) return ARSEG_EUNSUPPORTED;
+    }
     if (!head) return launch<0>(p, max_wgs, st);
     return n_cls <= 16 ? launch<1>(p, max_wgs, st) : launch<2>(p, max_wgs, st);
 }

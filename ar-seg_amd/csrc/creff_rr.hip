@@ -797,9 +797,11 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
     // the rolling kernel (creff_roll.hip) is the default; with more than 16 classes its head spills registers: the tile kernel then
-    if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16)))
-        return arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
-                                       log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, arseg_stream(stream));
+    if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16))) {
+        const int e = arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
+                                              log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, arseg_stream(stream));
+        if (e != ARSEG_EUNSUPPORTED || impl == ARSEG_CREFF_WARP_ROLL) return e;      // (a launch too large for its schedule table: the tile kernel)
+    }
     RRParams p;
     for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
     for (int i = N; i < MAXN; ++i) p.ref[i] = nullptr;
