@@ -36,6 +36,9 @@ class Config:
     conv_autotune    [ARSEG_CONV_AUTOTUNE = 1 | 0]              per-shape plans timed on first use (0: the library's tile heuristic)
     conv_find        [ARSEG_CONV_FIND = native | python]        who times the candidate plans: arseg_conv2d_find or the host loop
     conv_winograd    [ARSEG_CONV_WINOGRAD = 1 | 0]              let the tuner consider Winograd F(4x4,3x3)
+    conv_wino_margin [ARSEG_CONV_WINO_MARGIN = f]              Winograd is taken when f x its time (three launches, 6x the HBM bytes of the direct
+                                                               conv) is below the best direct plan's, both timed alone: in a step that shares HBM
+                                                               with other lanes the transforms run slower than alone
     conv_up2_taps    [ARSEG_CONV_UP2_TAPS = 1 | 0]              let the tuner consider the tap decomposition for convs after a x2 upsample
     conv_gemm_x3     [ARSEG_CONV_GEMM_X3 = 1 | wino | 0]        let the tuner consider the LDS-DMA GEMM on pre-split operands (csrc/gemm_x3.hip): for
                      the Winograd GEMMs, the 1x1 convs and the PSP bottleneck -> up_1 chain on split rows (1), the Winograd GEMMs only (wino)
@@ -54,6 +57,7 @@ class Config:
     conv_autotune: bool = True
     conv_find: str = "native"
     conv_winograd: bool = True
+    conv_wino_margin: float = 1.0
     conv_up2_taps: bool = True
     conv_gemm_x3: object = True          # True | "wino" | False
     conv_range_guard: str = "device"
@@ -69,7 +73,7 @@ class Config:
     def from_env(cls):
         e = os.environ.get
         return cls(conv_math=e("ARSEG_CONV_MATH", "f16x3"), conv_autotune=e("ARSEG_CONV_AUTOTUNE", "1") != "0",
-                   conv_find=e("ARSEG_CONV_FIND", "native"), conv_winograd=e("ARSEG_CONV_WINOGRAD", "1") != "0",
+                   conv_find=e("ARSEG_CONV_FIND", "native"), conv_winograd=e("ARSEG_CONV_WINOGRAD", "1") != "0", conv_wino_margin=float(e("ARSEG_CONV_WINO_MARGIN", "1.0") or 1.0),
                    conv_up2_taps=e("ARSEG_CONV_UP2_TAPS", "1") != "0", conv_gemm_x3={"0": False, "wino": "wino"}.get(e("ARSEG_CONV_GEMM_X3", "1"), True),
                    conv_range_guard={"1": "host", "host": "host", "0": "off", "off": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), "device"),
                    conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=int(e("ARSEG_CREFF_TY", "0") or 0),
@@ -85,6 +89,8 @@ def configure(**kw):
     for k, v in kw.items():          # validate everything before anything changes
         if not hasattr(config, k):
             raise _lib.ArsegError(f"unknown configuration key {k!r}")
+        if k == "conv_wino_margin" and not (isinstance(v, (int, float)) and v > 0):
+            raise _lib.ArsegError(f"conv_wino_margin must be a positive number, got {v!r}")
         if k == "conv_math" and v not in _MATH_NAMES:
             raise _lib.ArsegError(f"conv_math must be one of {sorted(_MATH_NAMES)}, got {v!r}")
         if k == "creff_warp_impl" and v not in ("", "roll", "tiles"):
@@ -906,7 +912,7 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 try:
                     t_direct = _time(lambda: launch(*plan, record=False))
                     launch_wino(record=False)                   # tunes the batched GEMM underneath
-                    if _time(lambda: launch_wino(record=False)) < t_direct:
+                    if _time(lambda: launch_wino(record=False)) * float(config.conv_wino_margin) < t_direct:
                         plan = "wino"
                 except _lib.ArsegError:
                     pass                                        # the Winograd route does not cover this shape: keep the direct plan
