@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--only-big", action="store_true")
     ap.add_argument("--seg-rows", type=int, default=0)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--fuzz", type=int, default=0, help="n random small shapes with random schedules (seg_rows, max_wgs) instead of the fixed list")
     args = ap.parse_args()
     from arseg_amd import _lib, ops, synth
     from arseg_amd.model import MyAttention
@@ -35,8 +36,8 @@ def main():
     pa = PackedAttention(m, dev)
     ops.configure(creff_seg_rows=args.seg_rows)
 
-    def run(impl, refs, mvq, lr, head, layout):
-        ops.configure(creff_warp_impl=impl)
+    def run(impl, refs, mvq, lr, head, layout, seg_rows=None, max_wgs=0):
+        ops.configure(creff_warp_impl=impl, creff_seg_rows=args.seg_rows if seg_rows is None else seg_rows, creff_max_wgs=max_wgs)
         return ops.creff_warp(refs, mvq, lr, pa, head, True, 7, 7, layout)
 
     def timeit(fn, iters):
@@ -55,13 +56,23 @@ def main():
     cases = [(12, 16, 6, 8, 1, 1, 12, _lib.C8), (10, 12, 5, 6, 2, 1, 12, _lib.NHWC), (7, 9, 3, 4, 1, 1, 19, _lib.C8),
              (32, 48, 16, 24, 2, 1, 12, _lib.NHWC), (33, 50, 16, 24, 1, 1, 0, _lib.C8), (64, 96, 32, 48, 3, 2, 12, _lib.NHWC),
              (140, 40, 70, 20, 2, 1, 12, _lib.C8), (300, 64, 150, 32, 1, 1, 12, _lib.NHWC)]
+    sched = {}
+    if args.fuzz:
+        fz = np.random.Generator(np.random.PCG64(2024))
+        cases = []
+        for i in range(args.fuzz):
+            Hp, Wp = int(fz.integers(2, 90)), int(fz.integers(2, 110))
+            hp, wp = int(fz.integers(1, Hp + 1)), int(fz.integers(1, Wp + 1))
+            case = (Hp, Wp, hp, wp, int(fz.integers(1, 5)), 1, int(fz.choice([0, 5, 12, 16])), int(fz.choice([_lib.C8, _lib.NHWC])))
+            cases.append(case)
+            sched[len(cases) - 1] = (int(fz.choice([0, 0, 2, 6, 14, 40])), int(fz.choice([0, 0, 1, 3, 7, 20, 100])))
     if args.only_big:
         cases = []
     if args.big or args.only_big:
         cases.append((512, 1024, 256, 512, 11, 1, 12, _lib.C8))
     g = np.random.Generator(np.random.PCG64(11))
     ok = True
-    for (Hp, Wp, hp, wp, B, mvd, n_cls, layout) in cases:
+    for ci, (Hp, Wp, hp, wp, B, mvd, n_cls, layout) in enumerate(cases):
         H, W = Hp * mvd, Wp * mvd
         big = Hp >= 512
         if big:
@@ -81,9 +92,10 @@ def main():
             head = (torch.from_numpy((0.2 * g.standard_normal((n_cls, C))).astype(np.float32)).to(dev),
                     torch.from_numpy((0.1 * g.standard_normal(n_cls)).astype(np.float32)).to(dev))
         p_t, l_t = run("tiles", refs, mvq, lr, head, layout)
-        p_r, l_r = run("roll", refs, mvq, lr, head, layout)
+        sr, mw = sched.get(ci, (None, 0))
+        p_r, l_r = run("roll", refs, mvq, lr, head, layout, sr, mw)
         torch.cuda.synchronize()
-        res = {"shape": [Hp, Wp, hp, wp, B, mvd, n_cls], "max_abs_p": float((p_t - p_r).abs().max()),
+        res = {"shape": [Hp, Wp, hp, wp, B, mvd, n_cls], "seg_rows": sr, "max_wgs": mw, "max_abs_p": float((p_t - p_r).abs().max()),
                "max_abs_logits": float((l_t - l_r).abs().max()) if n_cls else None,
                "nan": bool(torch.isnan(p_r).any())}
         if res["max_abs_p"] > 2.5e-4 or res["nan"] or (n_cls and res["max_abs_logits"] > 5e-4):      # (both kernels are within 1e-4 of the oracle)
