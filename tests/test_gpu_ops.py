@@ -1099,3 +1099,36 @@ def test_gop_graph_lanes(dev, independent):
     outs = g.replay()
     torch.cuda.synchronize()
     assert all(torch.equal(o, want2) for o in outs) and not torch.equal(want2, want)
+
+
+@pytest.mark.gpu
+def test_creff_roll_schedules_vs_oracle_random(dev):
+    """The rolling kernel on random small shapes (odd sizes, lr of any smaller size, 1-4 frames) under random schedules -- the balanced
+    default and fixed segments, few and many workgroups -- against the oracle's warp -> MyAttention: every piece list must cover every
+    pixel exactly once whatever the cut."""
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+    from oracle import cpu_ref
+
+    C = 64
+    fz = np.random.Generator(np.random.PCG64(77))
+    m = synth.load_synth_weights(MyAttention(C, kW=7, kH=7), 7, attn_gain=0.35)
+    sd = {kk: v.clone() for kk, v in m.state_dict().items()}
+    pa = PackedAttention(m, dev)
+    for case in range(24):
+        Hp, Wp = int(fz.integers(2, 60)), int(fz.integers(2, 70))
+        hp, wp, N = int(fz.integers(1, Hp + 1)), int(fz.integers(1, Wp + 1)), int(fz.integers(1, 5))
+        seg_rows, max_wgs = int(fz.choice([0, 0, 2, 6, 14, 40])), int(fz.choice([0, 0, 1, 3, 7, 20]))
+        refs = [rnd(100 + case * 8 + i, C, Hp, Wp) for i in range(N)]
+        lr = rnd(300 + case, N, C, hp, wp)
+        mvq = torch.from_numpy((fz.integers(-7, 8, (N, Hp, Wp, 2)) * 4 + fz.integers(0, 4, (N, Hp, Wp, 2))).astype(np.int16))
+        hr_w = torch.cat([cpu_ref.warp_feature(refs[i][None], cpu_ref.mv_resize(cpu_ref.mv_from_int16(mvq[i:i + 1]), Hp, Wp)) for i in range(N)])
+        want = cpu_ref.my_attention(sd, "", hr_w, lr, 7, 7)
+        refs_d = [r.permute(1, 2, 0).contiguous().to(dev) for r in refs]
+        prev = ops.configure(creff_warp_impl="roll", creff_seg_rows=seg_rows, creff_max_wgs=max_wgs)
+        try:
+            p, _ = ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, None, False, 7, 7, p_layout=_lib.NHWC)
+        finally:
+            ops.configure(**prev)
+        assert maxdiff(p.permute(0, 3, 1, 2), want) <= 1e-4, (case, Hp, Wp, hp, wp, N, seg_rows, max_wgs)
