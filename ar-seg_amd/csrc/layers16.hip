@@ -58,6 +58,44 @@ __global__ __launch_bounds__(256) void frame_to_nhwc8_kernel(const float *__rest
     }
 }
 
+// The same for the downscaling case with coalesced reads (the 16-bit twin of frame_to_nhwc4_rows_kernel, csrc/layers.hip): one workgroup =
+// 256 consecutive output pixels of one output row; the two source rows under it (x span of the 256 pixels, three planes) are staged in LDS
+// with 16-byte loads and the four taps of a pixel come from there -- the kernel above reads 12 strided scalars per pixel.  Same blend,
+// same operation order: bit-identical results.
+constexpr int F8_SPAN = 1056;                    // staged floats per row and plane: 255 * sx + 4 (+3 alignment) <= F8_SPAN  <=>  sx <= 4.1
+template <bool BF>
+__global__ __launch_bounds__(256) void frame_to_nhwc8_rows_kernel(const float *__restrict__ img, uint16_t *__restrict__ out, int N, int H, int W, int h, int w,
+                                                                  int segs) {
+    __shared__ __attribute__((aligned(16))) float st[6][F8_SPAN];
+    const float sy = arseg_resize_scale(H, h, true), sx = arseg_resize_scale(W, w, true);
+    const int seg = blockIdx.x % segs, oy = (blockIdx.x / segs) % h, n = blockIdx.x / (segs * h);
+    const int ox0 = seg * 256, ox1 = min(ox0 + 255, w - 1);
+    int y0, y1, xa, xb, xe0, xe1; float ly, lt;
+    arseg_src_index(sy, oy, true, H, y0, y1, ly);
+    arseg_src_index(sx, ox0, true, W, xa, xb, lt);
+    arseg_src_index(sx, ox1, true, W, xe0, xe1, lt);
+    ly = fminf(fmaxf(ly, 0.f), 1.f);
+    const int xs4 = xa & ~3, nch = (xe1 - xs4) / 4 + 1;        // 16-byte chunks per row and plane (W % 4 == 0: the last one stays inside the row)
+    const float *base = img + (size_t)n * 3 * H * W;
+    for (int i = threadIdx.x; i < 6 * nch; i += 256) {
+        const int r = i / nch, ch = i - r * nch, c = r >> 1, y = (r & 1) ? y1 : y0;
+        *reinterpret_cast<f32x4 *>(&st[r][4 * ch]) = *reinterpret_cast<const f32x4 *>(base + ((size_t)c * H + y) * W + xs4 + 4 * ch);
+    }
+    __syncthreads();
+    const int ox = ox0 + threadIdx.x;
+    if (ox < w) {
+        int x0, x1; float lx;
+        arseg_src_index(sx, ox, true, W, x0, x1, lx);
+        lx = fminf(fmaxf(lx, 0.f), 1.f);
+        x0 -= xs4; x1 -= xs4;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            v[c] = (1.f - ly) * ((1.f - lx) * st[2 * c][x0] + lx * st[2 * c][x1]) + ly * ((1.f - lx) * st[2 * c + 1][x0] + lx * st[2 * c + 1][x1]);
+        st8(out + (((size_t)n * h + oy) * w + ox) * 8, pack8<BF>(v));
+    }
+}
+
 // ------------------------------------------------------------------ nn.MaxPool2d(3, stride 2, padding 1)
 template <bool BF>
 __global__ __launch_bounds__(256) void maxpool16_kernel(const uint16_t *__restrict__ in, uint16_t *__restrict__ out, int N, int H, int W, int C, int Ho, int Wo) {
@@ -397,6 +435,14 @@ __global__ __launch_bounds__(256) void warp_mvq16_kernel(const uint16_t *__restr
 extern "C" int arseg_frame_to_nhwc8_16_fwd(const float *img, void *out, int dtype, int N, int H, int W, int h, int w, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(img); ARSEG_CHECK_PTR(out); ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(h); ARSEG_CHECK_POS(w);
     if (!ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    const int segs = arseg_cdiv(w, 256);
+    const float sx = arseg_resize_scale(W, w, true);
+    if (!(h == H && w == W) && W % 4 == 0 && ARSEG_ALIGNED16(img) && 255.f * sx + 8.f <= (float)F8_SPAN && (long long)N * h * segs < (1ll << 31)) {
+        const unsigned gr = (unsigned)(N * h * segs);
+        DISPATCH_BF(dtype, hipLaunchKernelGGL(frame_to_nhwc8_rows_kernel<true>, dim3(gr), dim3(256), 0, arseg_stream(stream), img, (uint16_t *)out, N, H, W, h, w, segs),
+                    hipLaunchKernelGGL(frame_to_nhwc8_rows_kernel<false>, dim3(gr), dim3(256), 0, arseg_stream(stream), img, (uint16_t *)out, N, H, W, h, w, segs));
+        return arseg_launch_status();
+    }
     const int g = grid_for((long long)N * h * w);
     DISPATCH_BF(dtype, hipLaunchKernelGGL(frame_to_nhwc8_kernel<true>, dim3(g), dim3(256), 0, arseg_stream(stream), img, (uint16_t *)out, N, H, W, h, w),
                 hipLaunchKernelGGL(frame_to_nhwc8_kernel<false>, dim3(g), dim3(256), 0, arseg_stream(stream), img, (uint16_t *)out, N, H, W, h, w));

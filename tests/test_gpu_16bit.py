@@ -287,3 +287,24 @@ def test_phase2_warp16_noninteger_ratio(dev, manifest, dtype):
     e_p, e_l = maxdiff(ops.from_c8(p_c8, _lib.NCHW), want_p), maxdiff(lo, want_lo)
     print(f"\n[{dtype}] phase2_warp 10x18 -> 21x37: p err {e_p:.3e} (max {float(want_p.abs().max()):.1f}), head logits err {e_l:.3e}")
     assert e_p <= 2e-4 * float(want_p.abs().max()) and e_l <= 2e-4 * max(float(want_lo.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("H,W,h,w", [(64, 1200, 32, 600), (36, 48, 18, 24), (35, 47, 17, 23), (20, 32, 20, 32)])
+def test_frame_ingest_16bit_equals_rounded_fp32(dev, dtype, H, W, h, w):
+    """frame_ingest to NHWC8 fp16 / bf16 -- the row-staged kernel (W % 4 == 0, downscale; several 256-pixel segments per row in the first
+    case), the per-pixel kernel (odd widths) and the copy case -- is the fp32 ingest (tests/test_gpu_ops.py pins that one to
+    F.interpolate) rounded to the storage type: same taps, same blend (the fp32 value may differ in its last bit between two kernels --
+    hipcc contracts the blend per kernel -- so the bound is one unit of the storage type, not equality)."""
+    from arseg_amd import ops
+
+    g = np.random.Generator(np.random.PCG64(91))
+    img = torch.from_numpy(g.standard_normal((2, 3, H, W)).astype(np.float32)).to(dev)
+    got = ops.frame_ingest(img, h, w, dtype)
+    ref = ops.frame_to_nhwc4(img, h, w)
+    assert got.shape == (2, h, w, 8) and got.dtype == dtype
+    ulp = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    assert bool(((got[..., :3].float() - ref[..., :3]).abs() <= ulp * ref[..., :3].abs() + 1e-7).all())
+    assert float((got[..., :3].float() != ref[..., :3].to(dtype).float()).float().mean()) < 1e-3      # (and nearly always the same rounding)
+    assert float(got[..., 3:].float().abs().max()) == 0.0
