@@ -5,17 +5,18 @@
 // Why a fourth kernel.  creff_rr.hip works on 16 x 16 tiles whose working set IS the compute unit (147 KB of LDS, key records OR value
 // records, never both), so its nine phases run one after the other and the VALU, the texture path, the LDS and the matrix pipe are busy
 // in turn (profiles/r03_creff_ablation.json).  Here a workgroup walks DOWN a 16-pixel-wide strip two rows at a time and keeps only what
-// the 7 x 7 windows of the current row pair need: 8 rows of key records and 10 rows of value records in two LDS rings (101 KB).  The
+// the 7 x 7 windows of the current row pair need: 8 rows of key records and 8 rows of value records in two LDS rings (2 x 45 KB).  The
 // halo shrinks from 2.25x (24 x 24 region per 16 x 16 tile) to 1.5x (gather) / 1.375x (records), and -- the point -- the stages of
 // DIFFERENT row pairs run at the same time on different waves (16 waves: 4 consumers, one per SIMD, and 12 producers):
 //
 //   producer waves 4..15                                           consumer waves 0..3 = (8-column query patch pc, key half kh)
-//   H1(t): taps of gather t+1 | blend gather t -> warp stage       H1(t): [kh 0: merge + residual + classifier + stores of step s-1]
+//   H1(t): taps of gather t | blend -> warp stage                  H1(t): [kh 0: merge + residual + classifier + stores of step s-1]
 //          lr_up rows of step t-4 -> lr_up stage                          Q.K^T + softmax of step s = t - 5 over the wave's key blocks
+//          value conv k = t-2 (rows in registers) -> value ring
 //   ---------------------------------------------------------------- barrier A
-//   H2(t): key + value conv k = t-1 -> rings | query conv s = t-4   H2(t): P.V over the wave's key blocks  [kh 1: partials -> LDS]
-//          residual record of step t-5 | requests of gather t+1
-//          (registers) | MVs of gather t+2
+//   H2(t): key conv k = t-1 -> key ring | query conv s = t-4        H2(t): P.V over the wave's key blocks  [kh 1: partials -> LDS]
+//          residual record of step t-5 | tap table of gather t+2           [kh 0: log-softmax + logits stores of step s-1]
+//          + touch of its lines | MVs of gather t+3
 //   ---------------------------------------------------------------- barrier B
 //
 // so the depthwise convolutions and the gather of rows further down run under the MFMAs of the rows being finished.  A producer lane
