@@ -59,7 +59,8 @@ PROTOTYPES = {
     "arseg_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, _STREAM]),
     "arseg_conv2d_find_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
-    "arseg_psp_w2_split_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _STREAM]),
+    "arseg_psp_w2_split_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_float, _STREAM]),
+    "arseg_creff_warp_select": (c_int, [c_int] * 12),
     "arseg_split_rows_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_gemm_x3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_gemm_x3_cat_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P,

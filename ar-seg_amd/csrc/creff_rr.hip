@@ -796,11 +796,13 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     if (seg_rows < 0 || max_wgs < 0) return ARSEG_EINVAL;
     for (int i = 0; i < N; ++i)
         if (!ref_nhwc_host[i] || !ARSEG_ALIGNED16(ref_nhwc_host[i])) return ARSEG_EINVAL;
-    // the rolling kernel (creff_roll.hip) is the default; with more than 16 classes its head spills registers: the tile kernel then
-    if (impl == ARSEG_CREFF_WARP_ROLL || (impl == ARSEG_CREFF_WARP_AUTO && (!head || n_cls <= 16))) {
+    // ONE dispatch rule (arseg_creff_warp_select states it, tests/test_gpu_ops.py::test_creff_dispatch_table enforces it): the rolling kernel
+    // (creff_roll.hip) serves every launch it admits -- no head or a head of <= 16 classes, a schedule that fits its piece table -- the
+    // 16 x 16 tile kernel below the rest (17-32 classes, oversized schedules) and impl = TILES
+    if (impl != ARSEG_CREFF_WARP_TILES) {
         const int e = arseg_creff_roll_launch(ref_nhwc_host, mv_q, H, W, lr, wq, bq, wk, bk, wv, bv, p_out, p_layout, wf, bf, n_cls, logits,
-                                              log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, arseg_stream(stream));
-        if (e != ARSEG_EUNSUPPORTED || impl == ARSEG_CREFF_WARP_ROLL) return e;      // (a launch too large for its schedule table: the tile kernel)
+                                              log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, false, arseg_stream(stream));
+        if (e != ARSEG_EUNSUPPORTED || impl == ARSEG_CREFF_WARP_ROLL) return e;
     }
     RRParams p;
     for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
@@ -819,6 +821,20 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     hipStream_t st = arseg_stream(stream);
     if (!head) return launch<0>(p, st);
     return n_cls <= 16 ? launch<1>(p, st) : launch<2>(p, st);
+}
+
+extern "C" int arseg_creff_warp_select(int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW, int n_cls, int impl, int seg_rows, int max_wgs) {
+    if (N <= 0 || C <= 0 || Hp <= 0 || Wp <= 0 || hp <= 0 || wp <= 0 || n_cls < 0 || seg_rows < 0 || max_wgs < 0) return ARSEG_EINVAL;
+    if (impl != ARSEG_CREFF_WARP_AUTO && impl != ARSEG_CREFF_WARP_TILES && impl != ARSEG_CREFF_WARP_ROLL) return ARSEG_EINVAL;
+    if (C != CH || kH != 7 || kW != 7 || N > MAXN || n_cls > 32) return ARSEG_EUNSUPPORTED;
+    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)N * C * hp * wp * sizeof(float) >= (1ull << 31) || (size_t)Hp * Wp >= (1u << 30))
+        return ARSEG_EUNSUPPORTED;
+    if (impl == ARSEG_CREFF_WARP_TILES) return ARSEG_CREFF_WARP_TILES;
+    const int e = arseg_creff_roll_launch(nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ARSEG_NHWC, nullptr,
+                                          nullptr, n_cls, nullptr, 0, N, Hp, Wp, hp, wp, seg_rows, max_wgs, true, nullptr);
+    if (e == ARSEG_OK) return ARSEG_CREFF_WARP_ROLL;
+    if (e != ARSEG_EUNSUPPORTED) return e;
+    return impl == ARSEG_CREFF_WARP_ROLL ? ARSEG_EUNSUPPORTED : ARSEG_CREFF_WARP_TILES;
 }
 
 extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,

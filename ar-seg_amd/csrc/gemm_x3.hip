@@ -328,8 +328,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 // The per-image second weight operand of arseg_gemm_x3_cat_fwd for the folded PSP bottleneck (model/pspnet.py:14-31), straight from the pyramid
 // terms: w2[n][co][k] = t[n][k][co] * unscale[co] for k < rows, 0 for rows <= k < 64, written as split rows (one thread = 4 consecutive k).
 __global__ __launch_bounds__(256) void psp_w2_split_kernel(const float *__restrict__ t, const float *__restrict__ unscale, unsigned char *__restrict__ out,
-                                                           int N, int rows, int Cout) {
+                                                           int N, int rows, int Cout, unsigned *range_flag, float range_limit) {
     const long long total = (long long)N * Cout * 16;
+    float vmax = 0.f;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const int k = (int)(idx & 15) * 4;
         const long long nc = idx >> 4;
@@ -339,12 +340,16 @@ __global__ __launch_bounds__(256) void psp_w2_split_kernel(const float *__restri
         f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = k + j < rows ? t[(n * rows + k + j) * Cout + co] * f : 0.f;
+        // (NaN compares false in fmaxf's favour of the other operand: the !(.. <= ..) form below catches it as the other watchers do not need to --
+        // a NaN here can only come from t, which the GEMM that produced t already multiplied)
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
         unsigned h01, h23, l01, l23;
         arseg_split_f16(v, h01, h23, l01, l23);
         unsigned char *o = out + nc * 256 + (k >> 5) * 128 + (k & 31) * 2;
         *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
         *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
     }
+    if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
 template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
@@ -375,15 +380,16 @@ int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
 
 }  // namespace
 
-extern "C" int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, arseg_stream_t stream) {
+extern "C" int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, void *range_flag,
+                                      float range_limit, arseg_stream_t stream) {
     ARSEG_CHECK_PTR(t); ARSEG_CHECK_PTR(unscale); ARSEG_CHECK_PTR(out);
     ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(rows); ARSEG_CHECK_POS(Cout);
     if (rows > 64) return ARSEG_EUNSUPPORTED;
-    if (!ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    if (!ARSEG_ALIGNED16(out) || (reinterpret_cast<uintptr_t>(range_flag) & 3)) return ARSEG_EINVAL;
     const long long total = (long long)N * Cout * 16;
     const long long blocks = (total + 255) / 256;
     hipLaunchKernelGGL(psp_w2_split_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, arseg_stream(stream), t, unscale,
-                       reinterpret_cast<unsigned char *>(out), N, rows, Cout);
+                       reinterpret_cast<unsigned char *>(out), N, rows, Cout, reinterpret_cast<unsigned *>(range_flag), range_limit > 0.0f ? range_limit : 65504.0f);
     return arseg_launch_status();
 }
 

@@ -12,6 +12,10 @@ mandates on top of it.  Two plans, both with ONE exchange
   HR forward and broadcasts ``ref_p``; the ``gop-1`` non-keyframes are dealt round-robin over the ranks (11 frames over 8
   ranks: 2 + 1, the imbalance SURVEY.md section 8e notes).
 
+* **local** (``local=True``; the zero-communication comparison line of SURVEY.md section 8e, not the mandated design): rank ``g`` keeps
+  GOP ``g`` whole -- its own keyframe and that GOP's ``gop-1`` non-keyframes -- and nothing is exchanged.  Same work per rank as the
+  batched plan, so the two rates differ by exactly what the exchange costs (``bench.py --gpus N`` prints both).
+
 Each non-keyframe needs only its own pixels, its own accumulated MV map and its GOP's ``ref_p`` -- no
 frame-to-frame recurrence (evaluation.py:161-193).  Outputs stay rank-local; only the confusion matrix
 is all-reduced (the reference's dormant ``dist.all_reduce(hist)``, evaluation.py:134-135).
@@ -55,18 +59,22 @@ class GopRunner:
     Returns {(gop index, d): output} for this rank's frames.
     """
 
-    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None):
+    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None, local: bool = False):
         self.key_fn, self.nonkey_fn = key_fn, nonkey_fn
         self.n_gops, self.gop, self.group = n_gops, gop, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.local = bool(local) and self.world > 1
+        self.timing = None           # enable_timing(): HIP events around the exchange and phase 1 of every run_overlapped step
         self.single_gop = n_gops < self.world
+        if self.local and self.single_gop:
+            raise ValueError("the local plan keeps whole GOPs per rank: it needs n_gops to be a multiple of the world size")
         if self.single_gop and n_gops != 1:
             raise ValueError(f"n_gops ({n_gops}) must be 1 (single-GOP plan) or a multiple of the world size ({self.world})")
         if not self.single_gop and n_gops % self.world:
             raise ValueError(f"n_gops ({n_gops}) must be a multiple of the world size ({self.world})")
-        self.plan = frame_plan(n_gops, gop, self.world)[self.rank]
         self.my_gops = [g for g in range(n_gops) if keyframe_owner(g, self.world) == self.rank]
+        self.plan = ([(g, d) for g in self.my_gops for d in range(1, gop)] if self.local else frame_plan(n_gops, gop, self.world)[self.rank])
         # gather buffer (1 GB at world 8 for the PSPNet feature) and side stream, one pair PER LAUNCH STREAM: steps rotated over several
         # streams run concurrently, and a single buffer would be overwritten by the next step's collective while this step's warp +
         # CReFF still read it (the side stream's wait on ITS launch stream orders a buffer's reuse behind its previous consumer)
@@ -98,6 +106,8 @@ class GopRunner:
         the owner (``like``: a tensor with the feature's shape / dtype / device for the ranks that own no keyframe)."""
         if self.world == 1:
             return list(local_refs)
+        if self.local:                    # whole GOPs per rank: the features never leave the rank (indexed by gop like the other plans)
+            return dict(zip(self.my_gops, local_refs))
         if self.single_gop:
             if self.rank == 0:
                 buf = local_refs[0].contiguous()
@@ -136,7 +146,7 @@ class GopRunner:
         mvs)``.  Phase 1 (frame downscale + LR backbone) does not read ``ref_p``, so the collective's latency hides behind it.  On
         CPU tensors (gloo tests) the exchange simply runs first; the result is identical."""
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
-        on_gpu = frames_stacked.is_cuda and self.world > 1
+        on_gpu = frames_stacked.is_cuda and self.world > 1 and not self.local
         if on_gpu:
             main = torch.cuda.current_stream()
             self._lane = main.cuda_stream
@@ -144,9 +154,20 @@ class GopRunner:
             if side is None:
                 side = self._side_streams[self._lane] = torch.cuda.Stream(device=frames_stacked.device)
             side.wait_stream(main)                                  # the HR forward has produced local_refs; the lane's previous step is done with its buffer
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.timing is not None else None
             with torch.cuda.stream(side):
+                if ev:
+                    ev[0].record()
                 refs = self.exchange(local_refs, like)
+                if ev:
+                    ev[1].record()
+            if ev:
+                ev[2].record()
             feat = phase1_fn(frames_stacked)                        # overlaps the collective
+            if ev:
+                ev[3].record()
+                nbytes = sum(r.numel() * r.element_size() for r in local_refs)
+                self.timing.append((ev, nbytes))
             main.wait_stream(side)
             for r in refs:
                 r.record_stream(main)
@@ -154,3 +175,29 @@ class GopRunner:
             refs = self.exchange(local_refs, like)
             feat = phase1_fn(frames_stacked)
         return phase2_fn(feat, [refs[g] for (g, _) in self.plan], mvs_stacked)
+
+    # ------------------------------------------------------------------ diagnostics of the exchange step (bench.py --gpus N)
+    def enable_timing(self, on: bool = True):
+        """Record HIP events around the side-stream collective and around phase 1 of every ``run_overlapped`` step from now on (cheap: four
+        event records per step).  ``exchange_stats()`` reads them."""
+        self.timing = [] if on else None
+
+    def exchange_stats(self):
+        """What the first multi-GPU run needs to be self-diagnosing: per step the collective's duration on the side
+        stream, the bytes this rank receives, the rate that implies, phase 1's duration on the main stream beside it, and whether the
+        exchange ended before phase 1 did (= hidden).  Synchronises the device.  None if nothing was recorded."""
+        if not self.timing:
+            return None
+        torch.cuda.synchronize()
+        ex = [e[0].elapsed_time(e[1]) for e, _ in self.timing]
+        p1 = [e[2].elapsed_time(e[3]) for e, _ in self.timing]
+        lag = [e[3].elapsed_time(e[1]) for e, _ in self.timing]           # > 0: the collective finished AFTER phase 1 (exposed by that much)
+        sent = self.timing[0][1]
+        peers = self.world - 1
+        recv = sent * peers if not self.single_gop else (0 if self.rank == 0 else sent)
+        n = len(ex)
+        ex_ms = sum(ex) / n
+        return {"steps": n, "plan": "broadcast" if self.single_gop else "all_gather", "exchange_ms": ex_ms, "exchange_ms_max": max(ex),
+                "phase1_ms": sum(p1) / n, "bytes_sent_per_rank": sent, "bytes_received_per_rank": recv,
+                "exchange_GBps_in": recv / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None,
+                "exposed_ms": sum(max(v, 0.0) for v in lag) / n, "hidden_behind_phase1": all(v <= 0.0 for v in lag)}

@@ -1,0 +1,524 @@
+"""The conv engine's host side: route and plan selection per layer shape (implicit GEMM / patch-resident 3x3 / Winograd / tap
+decomposition / LDS-DMA GEMM on split rows), the split-row activation carrier, the 16-bit storage path, the folded PSP bottleneck."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from .. import _lib
+from .._lib import ConvDesc, check
+from ._base import RANGE_LIMIT, _arm_range_watch, _need_gpu, _need_gpu16, _nhwc_ld, _ptr, _range_word, _stream, is16, workspace
+from ._config import config, set_conv_math, sw
+from ._plans import _PATCH_CFGS, _conv_candidates, _conv_plans, _time, _tune_conv
+from ._profile import launch, tagged
+from .layers import psp_prior_sum, resize_nhwc
+
+
+class SplitRows:
+    """An NHWC activation tensor stored as split rows -- per 32 channels 32 hi fp16 halves then 32 lo halves, the operand format of
+    arseg_gemm_x3_fwd (include/arseg_hip.h) -- in a float32-typed buffer ``t`` of the logical shape (the same 4 bytes per value).
+    Produced by ``conv2d(..., out_split=True)`` / ``split_rows``; consumed by ``conv2d`` (1x1 convs and the tap-decomposed conv after a
+    x2 upsample).  ``float()`` gives the fp32 tensor back (torch ops on the device; only fallback paths need it)."""
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+    shape = property(lambda self: self.t.shape)
+    device = property(lambda self: self.t.device)
+
+    def float(self):
+        n, h, w, c = self.t.shape
+        hl = self.t.view(torch.float16).view(n, h, w, c // 32, 2, 32).float()
+        return (hl[..., 0, :] + hl[..., 1, :]).reshape(n, h, w, c)
+
+
+def gemm_x3_enabled() -> bool:
+    return sw.GEMM_X3 is True and sw.math == _lib.MATH_F16X3 and not sw.RANGE_GUARD
+
+
+def split_rows(x: torch.Tensor) -> SplitRows:
+    """fp32 NHWC [N,H,W,C] (C % 32 == 0; may be a channel slice) -> SplitRows: one memory-bound pass (arseg_split_rows_fwd) that also
+    carries the operand range watch of the GEMM that will consume it."""
+    _need_gpu(x)
+    n, h, w, c = x.shape
+    t = torch.empty((n, h, w, c), dtype=torch.float32, device=x.device)
+    rw = _range_word(x.device) if sw.RANGE_MODE == "device" else None
+    launch("split_rows", _lib.load().arseg_split_rows_fwd, _ptr(x), _nhwc_ld(x), _ptr(t), n * h * w, c, 1.0, _ptr(rw), 65504.0, _stream())
+    return SplitRows(t)
+
+
+def _x3_eligible(pc, cin, residual, up2) -> bool:
+    return (gemm_x3_enabled() and not up2 and pc.R == 1 and pc.S == 1 and pc.stride == 1 and pc.pad == 0 and cin % 32 == 0 and cin == pc.cin_pad
+            and pc.cout % 4 == 0)
+
+
+def _conv1x1_x3(x, pc, residual=None, out=None, out_split=False, cfg=None, record=True):
+    """1x1 stride-1 conv on the LDS-DMA GEMM (csrc/gemm_x3.hip).  x: SplitRows, or fp32 NHWC (split by a pre-pass first).  cfg None: the
+    tile shape is timed on first use per (M, K, N)."""
+    lib = _lib.load()
+    xs = x if isinstance(x, SplitRows) else split_rows(x)
+    N, H, W, Cin = xs.shape
+    M, Cout, dev = N * H * W, pc.cout, xs.device
+    if out_split and Cout % 32:
+        out_split = False                    # split rows come in groups of 32 channels: such a layer writes plain fp32
+    if out_split:
+        out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    elif out is None:
+        out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    rw = _range_word(dev) if (out_split and sw.RANGE_MODE == "device") else None
+
+    def run(c, rec):
+        args = (_ptr(xs.t), _ptr(pc.w_h3), _ptr(out), M, Cout, Cin, Cout if out_split else _nhwc_ld(out), 1, 0, 0, 0, _ptr(pc.scale_h3), _ptr(pc.bias),
+                _ptr(residual), _nhwc_ld(residual) if residual is not None else 0, pc.act, pc.slope, 1 if out_split else 0, c, _ptr(rw), 65504.0, _stream())
+        if rec:
+            launch("conv2d", lib.arseg_gemm_x3_fwd, *args, flops=2 * M * Cin * Cout)
+        else:
+            check(lib.arseg_gemm_x3_fwd(*args), "gemm_x3")
+
+    if cfg is None:
+        key = ("x3", dev.index, M, Cin, Cout, bool(out_split), residual is not None)
+        cfg = _conv_plans.get(key)
+        if cfg is None:
+            if not sw.AUTOTUNE or torch.cuda.is_current_stream_capturing():
+                # no timing loop inside a graph capture / with the tuner off: the first tile shape the problem admits, un-timed and not cached
+                # (cfg 0 alone raised for a shape it rejects although another tile takes it)
+                for c in range(7):
+                    try:
+                        run(c, record)
+                        return SplitRows(out) if out_split else out
+                    except _lib.ArsegError as err:
+                        last = err
+                raise last
+            else:
+                best_t = float("inf")
+                for c in range(7):
+                    try:
+                        t = _time(lambda: run(c, False))
+                    except _lib.ArsegError:  # a tile shape this problem does not admit
+                        continue
+                    if t < best_t:
+                        cfg, best_t = c, t
+                if cfg is None:
+                    raise _lib.ArsegError(f"gemm_x3: no tile configuration accepts M={M} K={Cin} N={Cout}")
+                _conv_plans[key] = cfg
+    run(cfg, record)
+    return SplitRows(out) if out_split else out
+
+
+def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None,
+           tile_cfg: int = 0, split_k: int = 0, up2: bool = False, out_split: bool = False):
+    """x NHWC [N,H,W,Cin_pad] (may be a channel slice); pc: packing.PackedConv; out: optional NHWC (slice) view.
+    tile_cfg / split_k: 0 = use the cached per-shape plan (autotuned on first use).
+    up2: the conv input is the x2 bilinear (align_corners=False) upsample of ``x`` (PSPUpsample, model/pspnet.py:43-46);
+    the Winograd route applies it inside its input transform, the patch-resident direct plans while they stage their input patch;
+    the GEMM-tile plans materialise it first."""
+    if isinstance(x, SplitRows):
+        # an activation the producer already wrote as split rows: 1x1 convs go straight to the LDS-DMA GEMM, a 3x3 conv after a x2 upsample
+        # to its tap decomposition (whose low-resolution 1x1 conv is such a GEMM); anything else reads the fp32 form
+        n_, h_, w_, c_ = x.shape
+        if not up2 and _x3_eligible(pc, c_, residual, False):
+            return _conv1x1_x3(x, pc, residual, out, out_split)
+        if (up2 and gemm_x3_enabled() and sw.UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.dil == 1
+                and pc.cout % 4 == 0 and c_ % 32 == 0):
+            split_out = out_split and out is None and pc.cout % 32 == 0      # (the next layer is again a tap-decomposed upsample conv)
+            if out is None:
+                out = torch.empty((n_, 2 * h_, 2 * w_, pc.cout), dtype=torch.float32, device=x.device)
+            with tagged((n_, 2 * h_, 2 * w_, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, True, "taps(x3)", 2 * n_ * 4 * h_ * w_ * pc.cout * 9 * pc.cin)):
+                _conv_up2_taps(x, pc, out, True, split_out)
+            return SplitRows(out) if split_out else out
+        return conv2d(x.float(), pc, residual, out, tile_cfg, split_k, up2, out_split)
+    if is16(x):
+        return _conv2d16(x, pc, residual, out, up2, tile_cfg, split_k)
+    _need_gpu(x, residual, out)
+    if out_split and tile_cfg == 0 and split_k == 0 and out is None and _x3_eligible(pc, x.shape[3], residual, up2) and pc.cout % 32 == 0:
+        # the consumer takes split rows (e.g. the PSP bottleneck feeding up_1): this conv runs on the LDS-DMA GEMM and writes them
+        n_, h_, w_, c_ = x.shape
+        with tagged((n_, h_, w_, pc.cin, pc.cout, 1, 1, 1, False, "x3(split out)", 2 * n_ * h_ * w_ * pc.cout * pc.cin)):
+            return _conv1x1_x3(x, pc, residual, None, True)
+    if sw.RANGE_GUARD and sw.math == _lib.MATH_F16X3 and not (float(x.abs().max()) <= RANGE_LIMIT):      # (NaN compares false)
+        prev = set_conv_math("f32")
+        try:
+            return conv2d(x, pc, residual, out, 0, 0, up2)
+        finally:
+            set_conv_math(prev)
+    x_low = None
+    if up2:
+        x_low = x
+        n_, h_, w_, c_ = x.shape
+        if (tile_cfg and tile_cfg not in _PATCH_CFGS) or (not tile_cfg and (split_k or not sw.AUTOTUNE)):
+            x, x_low = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False), None          # explicit GEMM tile / heuristic plan: materialise
+        else:
+            # shape carrier; filled only if a plan without a fused upsample is chosen (the patch-resident plans and the Winograd
+            # route interpolate while they stage their input)
+            x = torch.empty((n_, 2 * h_, 2 * w_, c_), dtype=x.dtype, device="meta")
+    dev = x_low.device if x_low is not None else x.device
+    N, H, W, Cin = x.shape
+    if Cin != pc.cin_pad:
+        raise _lib.ArsegError(f"conv expects {pc.cin_pad} input channels (padded), got {Cin}")
+    d = ConvDesc()
+    in_ld_hi = Cin if x_low is not None else _nhwc_ld(x)
+    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, in_ld_hi
+    d.Cout = pc.cout
+    d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
+    d.act, d.prelu_slope = pc.act, pc.slope
+    d.tile_cfg, d.split_k = tile_cfg, split_k
+    d.math = math = sw.math
+    _arm_range_watch(d, dev)
+    w_dev, scale_dev = (pc.w_h3, pc.scale_h3) if math != _lib.MATH_F32 else (pc.w, pc.scale)
+    d.out_ld, d.res_ld = pc.cout, pc.cout     # provisional, for the shape query
+    lib = _lib.load()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    check(lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv_out_hw")
+    Ho, Wo = ho.value, wo.value
+    if out is None:
+        out = torch.empty((N, Ho, Wo, pc.cout), dtype=torch.float32, device=dev)
+    elif tuple(out.shape) != (N, Ho, Wo, pc.cout):
+        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(N, Ho, Wo, pc.cout)}")
+    d.out_ld = _nhwc_ld(out)
+    if residual is not None:
+        if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
+            raise _lib.ArsegError("residual shape mismatch")
+        d.res_ld = _nhwc_ld(residual)
+    flops = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
+
+    up_buf = []
+
+    def run_plan(cfg, sk, record=True):
+        xin = x
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        if x_low is not None:
+            if cfg in _PATCH_CFGS:                              # the patch-resident kernel upsamples while it stages its patch
+                xin, d.upsample2x, d.in_ld = x_low, 1, _nhwc_ld(x_low)
+            else:                                               # GEMM kernel on an upsampled input: materialise it
+                if not up_buf:
+                    up_buf.append(torch.empty((N, H, W, Cin), dtype=torch.float32, device=x_low.device))
+                xin = resize_nhwc(x_low, H, W, _lib.BILINEAR, False, out=up_buf[0])
+        d.tile_cfg, d.split_k = cfg, sk
+        nbytes = lib.arseg_conv2d_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, out.device) if nbytes else None
+        args = (ctypes.byref(d), _ptr(xin), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+        if record:
+            launch("conv2d", lib.arseg_conv2d_fwd, *args, flops=flops)
+        else:
+            check(lib.arseg_conv2d_fwd(*args), "conv2d")
+
+    def launch_wino(record=True):
+        _conv_wino(x if x_low is None else x_low, pc, residual, out, N, H, W, record, up2=x_low is not None)
+
+    def launch_taps(record=True):
+        _conv_up2_taps(x_low, pc, out, record)
+
+    def launch_x3(record=True):
+        _conv1x1_x3(x, pc, residual, out, False, None, record)
+
+    def find_native():
+        """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
+        fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
+        xin = x
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        if x_low is not None:
+            xin, d.upsample2x, d.in_ld = x_low, 1, _nhwc_ld(x_low)
+        nbytes = lib.arseg_conv2d_find_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, out.device) if nbytes else None
+        cfg, sk, us = ctypes.c_int(), ctypes.c_int(), ctypes.c_float()
+        st = lib.arseg_conv2d_find(ctypes.byref(d), _ptr(xin), _ptr(w_dev), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws),
+                                   nbytes, 3, ctypes.byref(cfg), ctypes.byref(sk), ctypes.byref(us), _stream())
+        d.upsample2x, d.in_ld = 0, in_ld_hi
+        if st > 0:
+            check(st, "conv2d_find")                                # a HIP error is not "no plan": raise it
+        return (cfg.value, sk.value) if st == _lib.ARSEG_OK else None
+
+    if tile_cfg == 0 and split_k == 0 and sw.AUTOTUNE:
+        key = (dev.index, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil, x_low is not None, math)
+        wino_ok = getattr(pc, "wino_u", None) is not None and sw.WINOGRAD
+        taps_ok = (x_low is not None and sw.UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
+                   and pc.dil == 1 and pc.cout % 4 == 0)
+        x3_ok = _x3_eligible(pc, Cin, residual, x_low is not None) and not wino_ok
+        plan = _conv_plans.get(key)
+        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or plan == "tapsf":      # a persisted plan whose route is switched off / gone: re-tune
+            plan = None
+        if plan is None:
+            plan = find_native() if sw.NATIVE_FIND else None
+            if plan is None:
+                plan = _tune_conv(run_plan, pc, N * Ho * Wo)
+            elif x_low is not None:
+                # with a fused upsample the library times only the patch-resident plans: also time the GEMM-tile plans on the materialised
+                # upsample and keep the faster
+                alt = _tune_conv(run_plan, pc, N * Ho * Wo, allow_patch=False)
+                if alt is not None and _time(lambda: run_plan(*alt, record=False)) < _time(lambda: run_plan(*plan, record=False)):
+                    plan = alt
+            if plan is None:
+                # nothing could be launched.  The one shape-independent cause is the 2 GiB limit of the kernels' 32-bit buffer
+                # offsets on a large batch: split the batch (as creff does) instead of caching a plan that never ran.
+                if N > 1 and x_low is None and max(x.numel(), out.numel()) * 4 >= (1 << 31):
+                    hN = N // 2
+                    conv2d(x[:hN], pc, None if residual is None else residual[:hN], out[:hN])
+                    conv2d(x[hN:], pc, None if residual is None else residual[hN:], out[hN:])
+                    return out
+                run_plan(0, 0)                                    # raises the library's own error
+            if wino_ok:
+                try:
+                    t_direct = _time(lambda: run_plan(*plan, record=False))
+                    launch_wino(record=False)                   # tunes the batched GEMM underneath
+                    if _time(lambda: launch_wino(record=False)) * float(config.conv_wino_margin) < t_direct:
+                        plan = "wino"
+                except _lib.ArsegError:
+                    pass                                        # the Winograd route does not cover this shape: keep the direct plan
+            if x3_ok:                                           # split pre-pass + LDS-DMA GEMM against the best implicit-GEMM plan
+                try:
+                    t_direct = _time(lambda: run_plan(*plan, record=False))
+                    launch_x3(record=False)                     # picks its tile shape
+                    if _time(lambda: launch_x3(record=False)) < t_direct:
+                        plan = "x3"
+                except _lib.ArsegError:
+                    pass
+            if taps_ok:
+                try:
+                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: run_plan(*plan, record=False)))
+                    launch_taps(record=False)                   # tunes the low-resolution GEMM underneath
+                    if _time(lambda: launch_taps(record=False)) < t_best:
+                        plan = "taps"
+                except _lib.ArsegError:
+                    pass
+            _conv_plans[key] = plan
+        with tagged((N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, x_low is not None, str(plan), flops)):
+            if plan == "wino":
+                launch_wino()
+            elif plan == "taps":
+                launch_taps()
+            elif plan == "x3":
+                launch_x3()
+            else:
+                run_plan(*plan)
+    else:
+        run_plan(tile_cfg, split_k)
+    return out
+
+
+def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
+    """conv2d on the 16-bit storage path: one MFMA per product (arseg_conv2d16_fwd), fp32 epilogue (pc.scale / pc.bias)."""
+    dt = _need_gpu16(x, residual, out)
+    if up2:
+        n_, h_, w_, c_ = x.shape
+        x = resize_nhwc(x, 2 * h_, 2 * w_, _lib.BILINEAR, False)
+    N, H, W, Cin = x.shape
+    w16, cin_pad = pc.weights16(x.dtype)
+    if Cin != cin_pad:
+        raise _lib.ArsegError(f"conv (16-bit) expects {cin_pad} input channels (padded to 8), got {Cin}")
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld = N, H, W, Cin, _nhwc_ld(x)
+    d.Cout = pc.cout
+    d.R, d.S, d.stride, d.pad, d.dil = pc.R, pc.S, pc.stride, pc.pad, pc.dil
+    d.act, d.prelu_slope = pc.act, pc.slope
+    d.tile_cfg = tile_cfg
+    d.out_ld, d.res_ld = pc.cout, pc.cout
+    lib = _lib.load()
+    ho, wo = ctypes.c_int(), ctypes.c_int()
+    check(lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)), "conv_out_hw")
+    Ho, Wo = ho.value, wo.value
+    cout_ld = (pc.cout + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((N, Ho, Wo, cout_ld), dtype=x.dtype, device=x.device)[..., :pc.cout]
+    elif tuple(out.shape) != (N, Ho, Wo, pc.cout):
+        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(N, Ho, Wo, pc.cout)}")
+    d.out_ld = _nhwc_ld(out)
+    if residual is not None:
+        if tuple(residual.shape) != (N, Ho, Wo, pc.cout):
+            raise _lib.ArsegError("residual shape mismatch")
+        d.res_ld = _nhwc_ld(residual)
+    d.split_k = split_k
+
+    def args():
+        nbytes = lib.arseg_conv2d16_workspace_bytes(ctypes.byref(d))
+        ws = workspace(nbytes, x.device) if nbytes else None
+        return (ctypes.byref(d), dt, _ptr(x), _ptr(w16), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual), _ptr(out), _ptr(ws), nbytes, _stream())
+
+    if tile_cfg == 0 and split_k == 0 and sw.AUTOTUNE:      # per-shape plan: tile / K-step variants x split-K timed once on the device
+        key = ("conv16", x.device.index, dt, N, H, W, Cin, pc.cout, pc.R, pc.S, pc.stride, pc.pad, pc.dil)
+        plan = _conv_plans.get(key)
+        if plan is None:
+            best_t = float("inf")
+            ktiles = (pc.R * pc.S * Cin + 63) // 64
+            for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):    # 5..8: patch-resident 3x3 plans, 9: the 7x7 stem kernel (EUNSUPPORTED for other shapes)
+                for sk in (0, 1, 2, 4, 8):
+                    if sk > 1 and (ktiles // sk < 3 or pc.cout % 8 or cfg >= 5):
+                        continue
+                    if cfg >= 5 and (sk == 1 or (cfg in (6, 8) and pc.cout <= 64)):
+                        continue
+                    d.tile_cfg, d.split_k = cfg, sk
+                    try:
+                        t = _time(lambda: check(lib.arseg_conv2d16_fwd(*args()), "conv2d16"))
+                    except _lib.ArsegError:
+                        continue
+                    if t < best_t:
+                        plan, best_t = (cfg, sk), t
+            _conv_plans[key] = plan = plan or (0, 0)
+        d.tile_cfg, d.split_k = plan
+    flops16 = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
+    with tagged((N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, bool(up2), "16-bit " + str((d.tile_cfg, d.split_k)), flops16)):      # per-layer table (profile.layers())
+        launch("conv2d", lib.arseg_conv2d16_fwd, *args(), flops=flops16)
+    return out
+
+
+def _conv_wino(x, pc, residual, out, N, H, W, record=True, up2=False):
+    """3x3 stride-1 conv as Winograd F(4x4,3x3): input transform -> 36 batched GEMMs -> output transform.  The GEMMs run either on the
+    implicit-GEMM kernel in batched 1x1 mode (plan = its tile_cfg) or, with the transformed activations written as split rows, on the
+    LDS-DMA kernel of csrc/gemm_x3.hip (plan = 100 + its tile_cfg); whichever was faster when the shape was first seen.
+    N,H,W: conv input size; with up2 ``x`` is the half-resolution tensor the input transform upsamples on the fly."""
+    lib = _lib.load()
+    Cin, Cout, dil = pc.cin_pad, pc.cout, pc.dil
+    T = lib.arseg_wino43_tiles(N, H, W, dil)
+    V = torch.empty((36, T, Cin), dtype=torch.float32, device=x.device)
+    M = torch.empty((36, T, Cout), dtype=torch.float32, device=x.device)
+    la = launch if record else (lambda name, fn, *a, **k: check(fn(*a), name))
+    # under f16x3 the transformed activations are stored scaled by 2^-4 (exact; undone in the output transform): B^T d B amplifies by up to
+    # 100, and unscaled the split-fp16 operand range would be left for |x| >~ 1.3e3
+    vs = 2.0 ** -4 if sw.math == _lib.MATH_F16X3 else 1.0
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.in_ld = 1, T, 1, Cin, Cin
+    d.Cout, d.out_ld, d.res_ld = Cout, Cout, Cout
+    d.R, d.S, d.stride, d.pad, d.dil = 1, 1, 1, 0, 1
+    d.act, d.prelu_slope = _lib.ACT_NONE, 0.0
+    d.batch, d.in_batch_stride, d.w_batch_stride, d.out_batch_stride = 36, T * Cin, Cout * Cin, T * Cout
+    d.math = math = sw.math
+    _arm_range_watch(d, x.device)          # the batched GEMM watches the transformed activations it multiplies
+    u_dev, scale_dev = (pc.wino_u_h3, pc.wino_scale_h3) if math != _lib.MATH_F32 else (pc.wino_u, pc.scale)
+    x3_ok = bool(sw.GEMM_X3) and math == _lib.MATH_F16X3 and Cin % 32 == 0 and Cout % 4 == 0
+    key = ("wino_gemm", x.device.index, T, Cin, Cout, math)
+    plan = _conv_plans.get(key)
+    if plan is not None and plan >= 100 and not x3_ok:
+        plan = None
+
+    def transform(split, la_):
+        if split:      # the transform is the last place that sees the GEMM's fp32 operands: it carries the range watch
+            la_("wino_input", lib.arseg_wino43_input_split_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs,
+                ctypes.c_void_p(d.range_flag), 65504.0, _stream())
+        else:
+            la_("wino_input", lib.arseg_wino43_input_fwd, _ptr(x), _nhwc_ld(x), _ptr(V), N, H, W, Cin, dil, 1 if up2 else 0, vs, _stream())
+
+    def gemm(cfg, rec):
+        if cfg >= 100:
+            fn, args = lib.arseg_gemm_x3_fwd, (_ptr(V), _ptr(u_dev), _ptr(M), T, Cout, Cin, Cout, 36, T * Cin * 4, Cout * Cin * 4, T * Cout,
+                                               _ptr(None), _ptr(None), _ptr(None), 0, _lib.ACT_NONE, 0.0, 0, cfg - 100, _ptr(None), 0.0, _stream())
+        else:
+            d.tile_cfg, d.split_k = cfg, 1
+            fn, args = lib.arseg_conv2d_fwd, (ctypes.byref(d), _ptr(V), _ptr(u_dev), _ptr(None), _ptr(None), _ptr(None), _ptr(M), _ptr(None), 0, _stream())
+        if rec:
+            launch("conv2d", fn, *args, flops=2 * 36 * T * Cin * Cout)
+        else:
+            check(fn(*args), "conv2d(batched)")
+
+    if plan is None:
+        quiet = lambda name, fn, *a, **k: check(fn(*a), name)      # noqa: E731
+        best, best_t = 0, float("inf")
+        transform(False, quiet)
+        for cfg in (0, 5, 6, 7, 8, 9, 10, 11, 12) + ((17, 18, 19) if math == _lib.MATH_F16X3 else ()):
+            if cfg in (5, 8, 9, 12, 17, 18, 19) and Cout <= 64:
+                continue
+            if cfg in (18, 19) and Cout <= 128:
+                continue
+            t = _time(lambda: gemm(cfg, False))
+            if t < best_t:
+                best, best_t = cfg, t
+        if x3_ok:
+            transform(True, quiet)
+            for cfg in range(100, 107):
+                t = _time(lambda: gemm(cfg, False))
+                if t < best_t:
+                    best, best_t = cfg, t
+        plan = _conv_plans[key] = best
+    transform(plan >= 100, la)
+    gemm(plan, record)
+    la("wino_output", lib.arseg_wino43_output_fwd, _ptr(M), _ptr(scale_dev), _ptr(pc.bias), _ptr(residual),
+       _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out), N, H, W, Cout, dil, pc.act, pc.slope, 1.0 / vs, _stream())
+
+
+sw.UP2_TAPS = config.conv_up2_taps
+sw.GEMM_X3 = config.conv_gemm_x3
+
+
+def _conv_up2_taps(x_low, pc, out, record=True, out_split=False):
+    """conv3x3(pad 1) of the x2 bilinear upsample of ``x_low`` by tap decomposition (csrc/upconv.hip): one 1x1 conv at low resolution
+    with the nine taps stacked along the output channels, then the gather that samples the nine planes at the shifted positions of the
+    upsampled image and applies the epilogue of ``pc``.  out_split: the gather writes ``out`` (contiguous, Cout % 32 == 0) as split rows."""
+    lib = _lib.load()
+    n, h, w, _ = x_low.shape
+    z = conv2d(x_low, pc.taps())
+    if out_split:
+        rw = _range_word(out.device) if sw.RANGE_MODE == "device" else None
+        fn, name = lib.arseg_upconv3x3_tap_gather_split_fwd, "up2_tap_gather"
+        args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), n, h, w, pc.cout, pc.act, pc.slope, _ptr(rw), 65504.0, _stream())
+    else:
+        fn, name = lib.arseg_upconv3x3_tap_gather_fwd, "up2_tap_gather"
+        args = (_ptr(z), 9 * pc.cout, _ptr(pc.scale), _ptr(pc.bias), _ptr(out), _nhwc_ld(out), n, h, w, pc.cout, pc.act, pc.slope, _stream())
+    if record:
+        launch(name, fn, *args)
+    else:
+        check(fn(*args), name)
+
+
+_psp_interp = {}
+
+
+def psp_x3_foldable(pc) -> bool:
+    """psp_bottleneck_x3 pre-divides the pyramid terms by the epilogue's per-channel scale: a channel whose folded scale is 0 (pruned /
+    zero-initialised gamma) or tiny would give inf / overflow the split range, so such a module stays on the prior-sum + residual path.
+    Decided once per packed conv (one host read at the first forward), cached."""
+    ok = pc.__dict__.get("_x3_foldable")
+    if ok is None:
+        sc = pc.scale_h3.detach().abs()
+        ok = pc.__dict__["_x3_foldable"] = bool(torch.isfinite(sc).all().item()) and float(sc.min().item()) > 1e-4 * max(float(sc.max().item()), 1e-30)
+    return ok
+
+
+def psp_bottleneck_x3(feats: torch.Tensor, t: torch.Tensor, pc, sizes, out_split: bool = True):
+    """PSPModule's folded bottleneck (model/pspnet.py:14-31) as ONE GEMM:  relu(W_f f + b + sum_s upsample(t_s))  with the pyramid sum written as
+    B . T -- B [H*W, 64] the bilinear interpolation matrix of the pooled rows (built once per shape by running psp_prior_sum on an identity, so it
+    holds exactly the weights that kernel applies), T the per-image pyramid terms -- and concatenated along K of the bottleneck GEMM
+    (arseg_gemm_x3_cat_fwd): [f | B] . [W_f ; T]^T.  The 92 MB prior tensor (written by one kernel, read back as a residual by the next) is
+    gone: two more K steps.  feats [N,H,W,C] fp32, t [N, rows, C_out] (rows = sum s^2 <= 64); returns SplitRows / tensor [N,H,W,C_out]."""
+    lib = _lib.load()
+    N, H, W, C = feats.shape
+    rows, Cout, dev = t.shape[1], pc.cout, feats.device
+    key = (dev.index, H, W, tuple(sizes))
+    B = _psp_interp.get(key)
+    if B is None:
+        eye = torch.zeros((1, rows, 64), dtype=torch.float32, device=dev)
+        eye[0, torch.arange(rows), torch.arange(rows)] = 1.0
+        B = _psp_interp[key] = split_rows(psp_prior_sum(eye, sizes, H, W))          # [1,H,W,64] split rows, shared by the batch
+    fac = pc.__dict__.get("_x3_unscale")
+    if fac is None:
+        fac = pc.__dict__["_x3_unscale"] = (1.0 / pc.scale_h3).contiguous()          # the epilogue multiplies the accumulator by scale_h3
+        # (a channel whose folded scale is 0 or tiny cannot be un-scaled: psp_x3_foldable() keeps such a module on the residual path)
+    # the per-image pyramid operand [N, Cout, 64] as split rows, straight from t (no torch arithmetic inside the step)
+    w2s = SplitRows(torch.empty((N, Cout, 1, 64), dtype=torch.float32, device=dev))
+    #  the un-scale factor can be large (psp_x3_foldable admits scale ratios up to 1e4): this pass carries the range watch of its operand
+    rw2 = _range_word(dev) if sw.RANGE_MODE == "device" else None
+    launch("psp_w2_split", lib.arseg_psp_w2_split_fwd, _ptr(t.contiguous()), _ptr(fac), _ptr(w2s.t), N, rows, Cout, _ptr(rw2), 65504.0, _stream())
+    xs = split_rows(feats)
+    out = torch.empty((N, H, W, Cout), dtype=torch.float32, device=dev)
+    rw = _range_word(dev) if (out_split and sw.RANGE_MODE == "device") else None
+
+    def run(c, rec):
+        args = (_ptr(xs.t), _ptr(pc.w_h3), _ptr(B.t), _ptr(w2s.t), _ptr(out), H * W, Cout, C, 64, Cout, N, H * W * C * 4, 0, 0, Cout * 64 * 4, H * W * Cout,
+                _ptr(pc.scale_h3), _ptr(pc.bias), pc.act, pc.slope, 1 if out_split else 0, c, _ptr(rw), 65504.0, _stream())
+        if rec:
+            launch("conv2d", lib.arseg_gemm_x3_cat_fwd, *args, flops=2 * N * H * W * (C + 64) * Cout)
+        else:
+            check(lib.arseg_gemm_x3_cat_fwd(*args), "gemm_x3_cat")
+
+    pkey = ("x3cat", dev.index, N, H * W, C, Cout, bool(out_split))
+    cfg = _conv_plans.get(pkey)
+    if cfg is None:
+        best_t = float("inf")
+        for c in range(7):
+            tm = _time(lambda: run(c, False))
+            if tm < best_t:
+                cfg, best_t = c, tm
+        _conv_plans[pkey] = cfg
+    with tagged((N, H, W, C, Cout, 1, 1, 1, False, "x3(cat, split out)", 2 * N * H * W * C * Cout)):
+        run(cfg, True)
+    return SplitRows(out) if out_split else out

@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--variant-steps", type=int, default=9)
     ap.add_argument("--conv-layers", metavar="FILE", help="also write the per-layer conv table (shape, plan, us, TFLOP/s, fraction of the MFMA peak) as JSON")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
+    ap.add_argument("--plan", choices=["both", "exchange", "local"], default="both",
+                    help="N > 1: `value` is always the mandated exchange plan; both / local also time SURVEY 8e's zero-communication comparison plan "
+                         "(whole GOP per rank) and print it as plans.local")
     ap.add_argument("--streams", type=int, default=6, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
     ap.add_argument("--joined-graph", action="store_true", help="capture the lanes into ONE graph with a join per replay (the round-2 executor) instead of one graph per lane")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured HIP graph (N = 1 only)")
@@ -157,6 +160,10 @@ def main():
                     "conv_frac_mfma": r.get("roofline_conv", {}).get("frac"), "parity": r.get("parity")}
             except Exception as exc:      # a variant must never take the headline line down with it
                 result["variants"][name] = {"error": repr(exc)}
+    if "variants" in result and "value" in result["variants"].get("psp_f32", {}):
+        # side by side at the top level: `value` is fp32 tensors with f16x3 conv arithmetic (22-bit operands, fp32 accumulate);
+        # this is the same workload on the fp32 MFMA -- the reference's own arithmetic
+        result["value_strict_f32"] = result["variants"]["psp_f32"]["value"]
     if world > 1 and backend != "nccl":
         result["rehearsal"] = f"backend {backend}, {world} ranks on {torch.cuda.device_count()} GPU(s): schedule check, not a measurement"
     if rank == 0:
@@ -212,13 +219,26 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             return ev.alter_res_batch_pred(lr, refs, imgs, mvq, SCALE)[0]
         return ev.alter_res_batch_fast(lr, refs, imgs, mvq, SCALE)[0]
 
-    def step():
-        with torch.no_grad():
-            if world > 1 and not fused_tail:
-                # the exchange of the keyframe features runs on a side stream while the LR backbone (which does not read them) proceeds
-                return runner.run_overlapped(keyframes, frames_b, mvs_b, lambda f: ev.alter_res_phase1(lr, f, SCALE),
+    def make_step(rn, fb, mb):
+        def step_():
+            with torch.no_grad():
+                if world > 1 and not fused_tail:
+                    # the exchange of the keyframe features runs on a side stream while the LR backbone (which does not read them) proceeds
+                    return rn.run_overlapped(keyframes, fb, mb, lambda f: ev.alter_res_phase1(lr, f, SCALE),
                                              lambda feat, refs, mvq: ev.alter_res_phase2(lr, feat, refs, mvq))
-            return runner.run_batched(keyframes, frames_b, mvs_b, batch_fn)
+                return rn.run_batched(keyframes, fb, mb, batch_fn)
+        return step_
+
+    step = step_main = make_step(runner, frames_b, mvs_b)
+    # SURVEY 8e's comparison line (N > 1): the zero-communication plan -- rank g keeps GOP g whole (its keyframe is the one it owns anyway), no
+    # exchange.  Same kernels, same work per rank; timed after the mandated plan with the same K, reported beside it as plans.local
+    step_local = None
+    if world > 1 and full and args.plan in ("both", "local"):
+        runner_l = GopRunner(key_fn, nonkey_fn, n_gops=world, gop=GOP, local=True)
+        g_own = runner_l.my_gops[0]
+        fl = torch.cat([torch.from_numpy(clips[g_own]["frames"][d:d + 1]) for _, d in runner_l.plan]).to(dev)
+        ml = torch.cat([torch.from_numpy(clips[g_own]["mv"][d:d + 1]) for _, d in runner_l.plan]).to(dev)
+        step_local = make_step(runner_l, fl, ml)
 
     # Consecutive GOPs are independent: rotating them over a few HIP streams lets the MFMA-bound backbone convs of one GOP
     # run beside the VALU/LDS-bound warp + CReFF kernels of another.  Every step is fully executed; the timed region is
@@ -234,10 +254,10 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             gop_graph = GopGraph([step] * len(streams), warmup=1, independent=not args.joined_graph)
         torch.cuda.synchronize()
 
-    def run_steps(k):
+    def run_steps(k, step=step):
         out = None
         i = 0
-        if gop_graph is not None:
+        if gop_graph is not None and step is step_main:
             with torch.cuda.stream(streams[0]):
                 while i + gop_graph.lanes <= k:
                     out = gop_graph.replay(join=False)[0]      # (the timed region ends in a device-wide synchronize)
@@ -248,13 +268,13 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             i += 1
         return out
 
-    def timed_region(k):
+    def timed_region(k, step=step):
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        o = run_steps(k)
+        o = run_steps(k, step)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -271,12 +291,39 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     _log("timed region")
     steps_requested = steps
     elapsed, outs = timed_region(steps)
+    requested_run = {"steps": steps, "timed_s": elapsed, "value": world * (GOP - 1) * steps / elapsed}      # the run the command line asked for, as timed
+    steps_note = None
     min_s = MIN_TIMED_S if full else 0.3 * MIN_TIMED_S          # variant lines: a shorter window, still far above launch jitter
     if elapsed < min_s:
         # the requested K steps are too short a window to trust (0.12 s at --steps 20): time a whole multiple of K that lasts
         # >= 1 s instead; the multiple follows from the max-over-ranks time, so every rank runs the same number of steps
         steps = steps_requested * int(math.ceil(1.05 * min_s / max(elapsed, 1e-6)))
         elapsed, outs = timed_region(steps)
+        steps_note = (f"--steps {steps_requested} lasted {requested_run['timed_s']:.3f} s ({requested_run['value']:.0f} frames/s, `requested_run`): shorter than the "
+                      f"{min_s:.1f} s this bench trusts, so `value` / `steps` / `ms_per_step` are from a second region of {steps} = {steps // steps_requested} x "
+                      f"{steps_requested} steps, timed the same way (barrier + synchronize on both sides, max over ranks)")
+    plans = None
+    if step_local is not None:
+        run_steps(max(2, warmup // 2), step_local)
+        l_el, _ = timed_region(steps, step_local)
+        plans = {"exchange": {"value": world * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+                              "what": "the mandated plan: frames dealt round-robin, one all-gather of the keyframe features per step on a side stream under phase 1"},
+                 "local": {"value": world * (GOP - 1) * steps / l_el, "ms_per_step": 1e3 * l_el / steps,
+                           "what": "SURVEY 8e comparison line: whole GOP per rank, no exchange (same kernels, same work per rank)"},
+                 "exchange_cost_frac": 1.0 - l_el / elapsed, "unit": "frames/s", "steps": steps}
+    exchange_stats = None
+    if world > 1 and full and not fused_tail:
+        # self-diagnosing exchange: a few more steps with HIP events around the side-stream collective and around phase 1
+        runner.enable_timing()
+        run_steps(2 * len(streams))
+        exchange_stats = runner.exchange_stats()
+        runner.enable_timing(False)
+        if exchange_stats is not None:          # every rank's view, worst case first: the slowest link decides the step
+            rows = [None] * world
+            dist.all_gather_object(rows, {"rank": rank, **{k: exchange_stats[k] for k in ("exchange_ms", "exchange_ms_max", "phase1_ms", "exposed_ms", "exchange_GBps_in", "hidden_behind_phase1")}})
+            exchange_stats["per_rank"] = sorted(rows, key=lambda r: -r["exchange_ms"])
+            exchange_stats["hidden_behind_phase1_all_ranks"] = all(r["hidden_behind_phase1"] for r in rows)
+            exchange_stats["backend"] = backend
 
     # N = 1 replays a captured HIP graph, N > 1 enqueues eagerly around the RCCL exchange: the eager rate of the same step at N = 1 is
     # timed as well, so that a multi-GPU number can be read against the right single-GPU one
@@ -301,7 +348,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                    "bise03_fp16": "non-keyframe frames/sec (backbone+CReFF), BiSeNet-18 1024x2048 / LR 0.3x 307x614, fp16"}[config],
         "value": nonkey_per_step * steps / elapsed,
         "unit": "frames/s",
-        "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "warmup": warmup, "timed_s": elapsed,
+        "n_gpus": world, "steps": steps, "steps_requested": steps_requested, "steps_note": steps_note, "requested_run": requested_run, "warmup": warmup, "timed_s": elapsed,
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
@@ -315,8 +362,12 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     }
     if eager is not None:
         result["eager_launches"] = eager
+    if plans is not None:
+        result["plans"] = plans
+    if exchange_stats is not None:
+        result["exchange"] = exchange_stats
     # operand range of the split-fp16 convs: the sticky device word, read once after the timed region (ops.range_tripped)
-    result["range_guard"] = {"mode": ops._RANGE_MODE, "tripped": bool(ops.range_tripped())}
+    result["range_guard"] = {"mode": ops.config.conv_range_guard, "tripped": bool(ops.range_tripped())}
 
     # ---- per-kernel timing with HIP events on the launch stream (one extra, instrumented step)
     _log(f"{result['value']:.1f} frames/s; per-kernel event pass")
@@ -433,7 +484,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             cre_i, wrp_i = isn.get("creff_warp", isn.get("creff", zero)), isn.get("warp_mvq", zero)
             conc_stage_ms = (cre_i["ms"] + wrp_i["ms"]) / (3 * len(streams) * nfr)      # 3 x lanes steps of nfr frames each were profiled
             conc_launch_ms = cre_i["ms"] / cre_i["launches"]
-        roll = fused and ops.config.creff_warp_impl != "tiles" and N_CLS <= 16
+        # which kernel ran: the library's own dispatch rule, queried (restating it here mislabelled launches that fell back to the tile kernel)
+        which = ops.creff_warp_kernel(nfr, C, Hp, Wp, max(hp_, 1), max(wp_, 1), N_CLS) if fused else "two-kernel"
+        roll = which == "roll"
         kname = ("creff_roll_kernel<NB>" if roll else "creff_rr_kernel<NB>") if fused else ("creff_mfma_kernel<NB,TY>" if C >= 128 else "creff_kernel<7,NC,TH>")
         kt = next((v for k, v in traffic_db.get("kernels", {}).items() if k.startswith(kname.split("<")[0])), None)
         result["roofline"] = {
@@ -555,7 +608,10 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                                             f"the PyTorch-CPU oracle, keyframe feature precomputed outside the sample; {reps[0]} warm-up + {reps[1]} "
                                             "timed runs at 16 threads, median; repeated at 32 and 64 threads (1 + 2 runs each; at os.cpu_count() "
                                             "threads the strip-wise oracle does not finish a frame in a minute): `cores` / `seconds` = the fastest "
-                                            "thread count, re-timed with 1 + 3 runs",
+                                            "thread count, re-timed with 1 + 3 runs.  Thread scaling is limited by the PORT, not by the host: the oracle "
+                                            "evaluates the 7x7 local attention in 16-row strips (oracle/cpu_ref.py _ROWS, which bounds its unfold buffer), "
+                                            "so beyond ~16 threads the strips' small torch ops oversubscribe -- this number is a property of the port's "
+                                            "tiling (the reference has no CPU implementation of localAttention at all)",
                                   "seconds": cpu_s, "seconds_all": samples,
                                   "thread_sweep_seconds": {str(k): v for k, v in sorted(sweep.items())}}
         if not full:

@@ -144,6 +144,13 @@ int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const int16_t *mv
                             float *logits, int log_softmax, int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW,
                             int impl, int seg_rows, int max_wgs, arseg_stream_t stream);
 
+/* Which kernel arseg_creff_warp_fwd_ex runs for a launch of this shape and these knobs -- a pure query, nothing is launched: returns
+ * ARSEG_CREFF_WARP_ROLL or ARSEG_CREFF_WARP_TILES (> 0), ARSEG_EUNSUPPORTED for shapes the fused entry point does not cover (or impl = ROLL on a
+ * launch the rolling kernel does not admit), ARSEG_EINVAL for bad arguments.  n_cls = 0: no head.  The rule: the rolling kernel serves every
+ * launch it admits (C == 64, 7 x 7, no head or <= 16 classes, a schedule that fits its 64-entry piece table); the tile kernel serves 17-32-class
+ * heads, oversized schedules and impl = TILES.  (bench.py labels its roofline line with this; tests enforce the table.) */
+int arseg_creff_warp_select(int N, int C, int Hp, int Wp, int hp, int wp, int kH, int kW, int n_cls, int impl, int seg_rows, int max_wgs);
+
 /* The same with the kernel choice made explicit (measurements, tests): impl = enum arseg_creff_impl (AUTO: the matrix-core kernel
  * for C >= 128, the VALU kernel otherwise); mfma_tile_rows = 0 (by launch size), 8 or 16.  No environment variables are read. */
 int arseg_creff_fwd_ex(const float *hr, const float *lr, const float *wq, const float *bq, const float *wk,
@@ -255,8 +262,11 @@ int arseg_wino43_output_fwd(const float *M, const float *scale, const float *bia
                             arseg_stream_t stream);
 
 /* The per-image pyramid operand of arseg_gemm_x3_cat_fwd for the folded PSP bottleneck (model/pspnet.py:14-31) in one pass:
- * out[n][co][k] (split rows, K = 64) = t[n][k][co] * unscale[co] for k < rows, 0 beyond.  t fp32 [N, rows, Cout], rows <= 64. */
-int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, arseg_stream_t stream);
+ * out[n][co][k] (split rows, K = 64) = t[n][k][co] * unscale[co] for k < rows, 0 beyond.  t fp32 [N, rows, Cout], rows <= 64.
+ * range_flag / range_limit: as in arseg_conv_desc -- this pass is where the fp32 values of that GEMM operand are last seen (un-scaled
+ * pyramid terms can leave the split-fp16 range when the folded scale of a channel is small); NULL: no watch. */
+int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int N, int rows, int Cout, void *range_flag, float range_limit,
+                           arseg_stream_t stream);
 
 /* (Part of the nn.Conv2d replacement above: the GEMM inside conv3x3 on the Winograd route, /root/reference/model/extractors.py:30-32,
  * the 1x1 bottleneck of PSPModule, model/pspnet.py:26, and the low-resolution tap GEMM of PSPUpsample, model/pspnet.py:38-46.)

@@ -23,3 +23,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/${TAG}_fetch -o f --output-for
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/${TAG}_write -o w --output-format csv -- $BENCH --no-profile > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 GRBM_GUI_ACTIVE -d $OUT/${TAG}_mfma -o m --output-format csv -- $BENCH --no-profile > /dev/null 2>&1
 python $R/tools/summarize_profile.py $OUT $TAG
+# the raw traces are tens of MB each; gpurun merges at most 64 MiB back: keep the summaries only (KEEP_RAW=1 keeps everything)
+[ -n "$KEEP_RAW" ] || rm -rf $OUT/${TAG}_stats $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_mfma

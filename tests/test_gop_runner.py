@@ -49,9 +49,11 @@ def _worker(rank, world, port, q, mode="batched"):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gops = 1 if mode == "single" else world
     keys, frames, mvs = _data(n_gops)
-    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops)
+    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops, local=mode.startswith("local"))
     like = torch.empty(3, 8, 8)
-    if mode == "overlapped":        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
+    if mode.startswith("local"):
+        assert runner.plan == [(rank, d) for d in range(1, 12)]       # whole GOP `rank`, nothing from the other ranks' GOPs
+    if mode in ("overlapped", "local-overlapped"):        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
         fs = torch.stack([frames[f] for f in runner.plan])
         ms = torch.stack([mvs[f] for f in runner.plan])
         res = runner.run_overlapped({g: keys[g] for g in runner.my_gops}, fs, ms, _phase1, _phase2)
@@ -69,11 +71,12 @@ import pytest
 
 
 @pytest.mark.parametrize("world,mode", [(2, "batched"), (2, "overlapped"), (2, "single"), (4, "batched"), (4, "single"),
-                                        (8, "overlapped"), (8, "single")])
+                                        (8, "overlapped"), (8, "single"), (2, "local"), (4, "local-overlapped")])
 def test_multi_rank_gloo_matches_single_process(world, mode):
     """world 2 / 4 / 8 over gloo == the single-process run, bit for bit: the batched plan (all-gather), the overlapped schedule (exchange
     concurrent with phase 1) and the single-GOP plan (owner broadcasts ref_p, 11 frames dealt over the ranks -- at world 8 three ranks
-    get two frames and five get one: the literal north-star configuration, BASELINE configs[3] is the batched plan at world 8)."""
+    get two frames and five get one: the literal north-star configuration, BASELINE configs[3] is the batched plan at world 8); and the
+    zero-communication comparison plan of SURVEY 8e ("local": rank g keeps GOP g whole, no collective on the data path)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -817,7 +817,7 @@ def test_conv2d_range_guard(dev, monkeypatch):
             assert ops.range_tripped(), cfg
             ops.conv2d(xd * 1e-4, pc, tile_cfg=cfg, split_k=1)
             assert not ops.range_tripped(), cfg
-        monkeypatch.setattr(ops, "_RANGE_GUARD", True)          # the host-synchronising validation mode
+        monkeypatch.setattr(ops._config.sw, "RANGE_GUARD", True)          # the host-synchronising validation mode
         e_host = rel(ops.conv2d(xd, pc), want)
         assert ops._math == _lib.MATH_F16X3
     finally:
@@ -848,6 +848,51 @@ def test_range_guard_winograd_and_evaluator(dev):
         assert ops.range_tripped()
     finally:
         ops.set_conv_math(prev)
+
+
+def test_range_guard_psp_pyramid_operand(dev):
+    """ The per-image pyramid operand of the folded PSP bottleneck is un-scaled by 1 / scale[co] before it is split: a channel with a
+    small folded scale can push it beyond 65504.  arseg_psp_w2_split_fwd carries the range watch of that operand (ABI level and through
+    ops.psp_bottleneck_x3), as every other producer of split rows does."""
+    import ctypes
+
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    lib = _lib.load()
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda a: ctypes.c_void_p(a.data_ptr() if a is not None else None)      # noqa: E731
+    N, rows, Cout = 2, 50, 64
+    tt = rnd(700, N, rows, Cout).to(dev)
+    un = torch.ones(Cout, device=dev)
+    out = torch.empty((N, Cout, 64), dtype=torch.float32, device=dev)
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    _lib.check(lib.arseg_psp_w2_split_fwd(P(tt), P(un), P(out), N, rows, Cout, P(word), 65504.0, st), "psp_w2_split")
+    assert int(word.item()) == 0
+    got = ops.SplitRows(out.view(N, Cout, 1, 64)).float().reshape(N, Cout, 64)
+    assert maxdiff(got[:, :, :rows], tt.permute(0, 2, 1)) <= 2e-6 * float(tt.abs().max()) and float(got[:, :, rows:].abs().max()) == 0.0
+    un[7] = 1e6                                                # one channel whose folded scale is tiny
+    _lib.check(lib.arseg_psp_w2_split_fwd(P(tt), P(un), P(out), N, rows, Cout, P(word), 65504.0, st), "psp_w2_split")
+    assert int(word.item()) == 1
+    _lib.check(lib.arseg_psp_w2_split_fwd(P(tt), P(un), P(out), N, rows, Cout, None, 0.0, st), "psp_w2_split")      # no watch: allowed
+    assert lib.arseg_psp_w2_split_fwd(P(tt), P(un), P(out), N, rows, Cout, ctypes.c_void_p(word.data_ptr() + 1), 65504.0, st) == _lib.ARSEG_EINVAL
+    # through the host layer: a bottleneck whose channel 5 has a scale of 3e-4 x the others (still foldable) and pyramid terms of ~1e3
+    C, H, W, sizes = 64, 12, 16, (1, 2, 3, 6)
+    w = rnd(701, 128, C, scale=0.1)
+    gamma = torch.ones(128); gamma[5] = 3e-4
+    pc = PackedConv(w, None, (gamma, torch.zeros(128), torch.zeros(128), torch.ones(128)), act=_lib.ACT_RELU, device=dev)
+    assert ops.psp_x3_foldable(pc)
+    feats = rnd(702, 1, H, W, C).to(dev)
+    prev = ops.configure(conv_math="f16x3", conv_range_guard="device", conv_gemm_x3=True)
+    try:
+        ops.range_tripped()
+        ops.psp_bottleneck_x3(feats, rnd(703, 1, 50, 128).to(dev), pc, sizes)
+        assert not ops.range_tripped()
+        ops.psp_bottleneck_x3(feats, (rnd(703, 1, 50, 128) * 1e3).to(dev), pc, sizes)          # 1e3 / 3e-4 > 65504 in channel 5
+        assert ops.range_tripped()
+    finally:
+        ops.configure(**prev)
+        ops.range_tripped()
 
 
 @pytest.mark.parametrize("H,W,h,w", [(36, 48, 18, 24), (35, 47, 17, 23), (20, 30, 20, 30)])

@@ -89,3 +89,46 @@ def test_split_rows_layout_matches_host_packer():
     sr = ops.SplitRows(torch.from_numpy(out).reshape(2, 3, 4, K))
     assert sr.shape == (2, 3, 4, K)
     assert torch.equal(sr.float(), torch.from_numpy(hi + lo).reshape(2, 3, 4, K))
+
+
+def test_config_validation_is_the_same_for_env_and_configure(monkeypatch):
+    """ A typo in an A/B run must not silently measure the default kernel: the environment is held to configure()'s rules."""
+    from arseg_amd import _lib, ops
+
+    for var, bad in (("ARSEG_CREFF_WARP_IMPL", "rol"), ("ARSEG_CONV_WINO_MARGIN", "0"), ("ARSEG_CONV_WINO_MARGIN", "-1"), ("ARSEG_CONV_MATH", "fp32"),
+                     ("ARSEG_CREFF_TY", "12"), ("ARSEG_CONV_RANGE_GUARD", "devcie"), ("ARSEG_CREFF_MAX_WGS", "-3"), ("ARSEG_LR_SUBBATCH", "x")):
+        monkeypatch.setenv(var, bad)
+        with pytest.raises(_lib.ArsegError):
+            ops.Config.from_env()
+        monkeypatch.delenv(var)
+    for kw in ({"creff_warp_impl": "rol"}, {"conv_wino_margin": 0}, {"conv_math": "fp32"}, {"creff_tile_rows": 12}, {"creff_max_wgs": -1}, {"conv_range_guard": "x"}):
+        with pytest.raises(_lib.ArsegError):
+            ops.configure(**kw)
+    assert ops.Config.from_env() == ops.Config()
+
+
+def test_creff_dispatch_table():
+    """ONE dispatch story for the fused warp + CReFF entry point, stated by the library itself (arseg_creff_warp_select, a
+    pure query: no GPU needed) -- DESIGN.md 5.2 holds the same table:
+        rolling kernel  (creff_roll.hip)  C = 64, 7 x 7, no head or <= 16 classes, schedule fits its piece table
+        tile kernel     (creff_rr.hip)    17-32 classes, schedules the rolling kernel does not admit, impl = TILES
+        two kernels     (warp_mvq + creff_mfma / creff)   everything else (C != 64, other windows)
+    and the advisor's example of round 4 (fixed 128-row segments of a 720 x 960 x 11 launch on 8 workgroups = 83 pieces per workgroup, more than the
+    64-entry table) is refused by the rolling kernel instead of being computed in part."""
+    from arseg_amd import _lib
+
+    sel = _lib.load().arseg_creff_warp_select
+    AUTO, TILES, ROLL = 0, 1, 2
+    q = lambda N, C, Hp, Wp, n_cls, impl=AUTO, seg=0, wgs=0, k=7: sel(N, C, Hp, Wp, Hp // 2, Wp // 2, k, k, n_cls, impl, seg, wgs)      # noqa: E731
+    assert q(11, 64, 512, 1024, 12) == ROLL and q(11, 64, 512, 1024, 0) == ROLL and q(11, 64, 512, 1024, 16) == ROLL
+    assert q(3, 64, 1024, 2048, 12) == ROLL and q(1, 64, 7, 9, 0) == ROLL
+    assert q(11, 64, 512, 1024, 19) == TILES and q(11, 64, 512, 1024, 32) == TILES                  # 17-32 classes: the tile kernel
+    assert q(11, 64, 512, 1024, 19, ROLL) == _lib.ARSEG_EUNSUPPORTED                                # ... and never the rolling kernel
+    assert q(11, 64, 512, 1024, 12, TILES) == TILES
+    assert q(11, 64, 720, 960, 12, AUTO, 128, 8) == TILES                                           # 83 pieces per workgroup
+    assert q(11, 64, 720, 960, 12, ROLL, 128, 8) == _lib.ARSEG_EUNSUPPORTED
+    assert q(11, 64, 720, 960, 12, AUTO, 128, 0) == ROLL
+    for args in ((11, 256, 128, 256, 19), (11, 64, 512, 1024, 33), (33, 64, 64, 64, 12)):             # not the fused entry point's shapes
+        assert q(*args) == _lib.ARSEG_EUNSUPPORTED
+    assert q(11, 64, 512, 1024, 12, k=5) == _lib.ARSEG_EUNSUPPORTED
+    assert q(11, 64, 512, 1024, 12, 7) == _lib.ARSEG_EINVAL and q(0, 64, 8, 8, 0) == _lib.ARSEG_EINVAL
