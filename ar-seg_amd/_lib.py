@@ -20,6 +20,8 @@ FLOW_F32, FLOW_F64 = 0, 1
 NEAREST, BILINEAR = 0, 1
 REDUCE_MEAN, REDUCE_MAX = 0, 1
 MATH_F32, MATH_F16X3, MATH_F16 = 0, 1, 2
+ROWS_X3, ROWS_F16, ROWS_BF16 = 0, 1, 2          # enum arseg_rows_fmt
+ROWS_OUT_NHWC, ROWS_OUT_PADDED = 0, 1          # enum arseg_rows_out
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
@@ -61,6 +63,9 @@ PROTOTYPES = {
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
     "arseg_psp_w2_split_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_creff_warp_select": (c_int, [c_int] * 12),
+    "arseg_conv3x3_rows_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, c_float, _STREAM]),
+    "arseg_gemm_rows16_fwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_float, c_int, _STREAM]),
+    "arseg_pad_rows_fwd": (c_int, [_P, c_int64, _P] + [c_int] * 6 + [_P, c_float, _STREAM]),
     "arseg_split_rows_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_gemm_x3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_gemm_x3_cat_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P,

@@ -18,11 +18,23 @@
 //     buffered, ONE barrier per K step; tile_cfg 6 runs the 16 waves of a 256 x 256 tile as two groups half a K step apart (see STAG below):
 //     while one group issues MFMAs the other reads fragments and requests the next step (-12 % on the largest GEMM);
 //   * D is computed transposed (weights as the MFMA's A operand) so that a lane holds 4 consecutive output channels: 16-byte stores.
+//
+// (r5) Two generalisations of the same kernel, both without a byte of im2col or a register-staged operand:
+//   * IMPLICIT 3x3 (taps == 9).  The activation operand is a zero-bordered ("padded") NHWC image [N][H + 2d][W + 2d][Cin] in the row format, and
+//     GEMM row m IS padded pixel m: tap t of a 3x3 conv with padding == dilation == d reads row m + ((t / 3 - 1) * (W + 2d) + (t % 3 - 1)) * d.
+//     A K step is (tap, 128-byte channel group): the tap is one scalar added to every lane's DMA source offset, the padding is the image's own
+//     zero border, rows in front of / behind the buffer are the buffer descriptor's out-of-range zero.  Border rows of the output are garbage and
+//     are either dropped (out_mode NHWC: the rows are compacted to the unpadded image) or written as zeros (out_mode PADDED: the output is the next
+//     3x3 conv's operand, same geometry).  Cost of the border: (H + 2d)(W + 2d) / HW rows computed -- 1.05 at 64 x 128, 1.10 at 32 x 64, d = 1.
+//   * 16-BIT ROWS (FMT 1 = fp16, 2 = bf16): a row is K values of 2 bytes, a K step is still 128 bytes = 64 values = two v_mfma_f32_16x16x32 per
+//     fragment pair instead of the three of the hi/lo emulation; the same DMA image, the same swizzle, the same fragment reads (slot kq = k 8kq..,
+//     slot 4 + kq = k 32 + 8kq..).  The 16-bit storage path's 1x1 and 3x3 stride-1 convs (BASELINE configs[2] / [4]) run on it.
 #include "arseg_common.h"
 
 namespace {
 
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct GX3Params {
@@ -41,6 +53,12 @@ struct GX3Params {
     float slope;
     unsigned *range_flag;             // out_split: set when a value written as a split row exceeds range_limit (arseg_conv_desc.range_flag)
     float range_limit;
+    // implicit 3x3 (taps == 9, K = 9 * Cin): see the header comment.  taps == 1: a plain GEMM.
+    int taps, kg;                     // kg = 128-byte K steps per tap
+    int pH, pW, pad, dil, iH, iW;     // padded image extent, border width (= the conv's padding), dilation, unpadded extent
+    int out_mode;                     // 0: row m -> row m; 1: padded row -> unpadded NHWC row (border rows dropped); 2: padded row kept, border rows written as zeros
+    const unsigned char *res_rows;    // residual in the ACTIVATION's row format at the same row index m (out_mode 2 chains: the block input); else p.res (plain, at the output row)
+    unsigned ldx;                     // bytes per activation row (K / taps values)
 };
 
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
@@ -56,9 +74,17 @@ __device__ __forceinline__ void dma16_buf(const u32x4 rsrc, unsigned voff, unsig
                  : "=&s"(keep) : "s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
 
-// NWM x NWN waves; 16-row fragments per wave: WTM along M (activation rows), WTN along N (weight rows)
-template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
+typedef __bf16 b16x8 __attribute__((ext_vector_type(8)));
+template <int FMT>
+__device__ __forceinline__ f32x4 mfma16(const h16x8 a, const h16x8 b, const f32x4 c) {
+    if constexpr (FMT == 2) return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(b16x8, a), __builtin_bit_cast(b16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// NWM x NWN waves; 16-row fragments per wave: WTM along M (activation rows), WTN along N (weight rows); FMT 0: split rows (f16x3), 1: fp16 rows, 2: bf16 rows
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false, int FMT = 0>
 __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params p) {
+    constexpr unsigned EB = FMT == 0 ? 4u : 2u;           // bytes per operand value
     constexpr int NW = NWM * NWN, BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
     constexpr int XB = BM * 128, WB = BN * 128, STAGE = XB + WB;
     constexpr int XI = BM / (8 * NW), WI = BN / (8 * NW);  // DMA instructions per wave and K step (8 rows each)
@@ -80,10 +106,10 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     const int wm = wave / NWN, wn = wave % NWN;
     const u32x4 x_rsrc = make_rsrc(p.X + (size_t)b * p.x_bs, p.x_bytes);
     const u32x4 w_rsrc = make_rsrc(p.W + (size_t)b * p.w_bs, p.w_bytes);
-    const unsigned ld = (unsigned)p.K * 4u, ld2 = (unsigned)p.K2 * 4u;
+    const unsigned ld = (unsigned)p.K * EB, ld2 = (unsigned)p.K2 * EB, ldx = p.ldx;
     const u32x4 x2_rsrc = make_rsrc(p.K2 ? p.X2 + (size_t)b * p.x2_bs : p.X, p.K2 ? p.x2_bytes : 0u);
     const u32x4 w2_rsrc = make_rsrc(p.K2 ? p.W2 + (size_t)b * p.w2_bs : p.W, p.K2 ? p.w2_bytes : 0u);
-    const int k1 = p.K >> 5;
+    const int k1 = (int)(ld >> 7);
 
     // DMA: lane (r8, pos) of instruction j fills LDS row wave*rows + 8j + r8, 16-byte position pos, with source slot pos ^ g(row)
     const int r8 = lane >> 3, pos = lane & 7;
@@ -92,7 +118,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     for (int j = 0; j < XI; ++j) {
         const int row = wave * (BM / NW) + j * 8 + r8;
         const unsigned gr = (unsigned)min(m0 + row, p.M - 1), sl = (unsigned)((pos ^ ((row >> 1) & 7)) << 4);
-        xsrc[j] = gr * ld + sl;
+        xsrc[j] = gr * ldx + sl;
         xsrc2[j] = gr * ld2 + sl;
     }
 #pragma unroll
@@ -103,19 +129,39 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
         wsrc2[j] = gr * ld2 + sl;
     }
     const unsigned lds0 = lds_addr(smem);
+    // implicit 3x3: K step kt = (tap, group) -> byte offset of the step inside the activation rows = tap row offset * ldx + group * 128
+    // (may be "negative": the 32-bit sum then lies beyond the buffer and the descriptor returns zeros -- only border rows read there)
+    const int kg = p.kg, taps = p.taps, pWd = p.pW * p.dil, dil = p.dil;
+    auto xstep = [&](int kt) -> unsigned {
+        if (taps == 1) return (unsigned)kt * 128u;
+        const int tap = kt / kg, g = kt - tap * kg, ty = tap / 3, tx = tap - 3 * ty;
+        return (unsigned)((ty - 1) * pWd + (tx - 1) * dil) * ldx + (unsigned)g * 128u;
+    };
+    // (two explicit arms: a `second ? xsrc2[j] : xsrc[j]` select made hipcc index the offset arrays through scratch -- a scratch load and a
+    // vmcnt(0) behind every DMA request)
     auto issue_x = [&](int kt, int st) {
-        const bool second = kt >= k1;                  // (uniform) the K steps of the concatenated second operand pair
-        const unsigned kb = (unsigned)(second ? kt - k1 : kt) * 128u, base = lds0 + (unsigned)st * STAGE;
-        const u32x4 rs = second ? x2_rsrc : x_rsrc;
+        const unsigned base = lds0 + (unsigned)st * STAGE;
+        if (kt >= k1) {                                // (uniform) the K steps of the concatenated second operand pair
+            const unsigned kb = (unsigned)(kt - k1) * 128u;
 #pragma unroll
-        for (int j = 0; j < XI; ++j) dma16_buf(rs, (second ? xsrc2[j] : xsrc[j]) + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
+            for (int j = 0; j < XI; ++j) dma16_buf(x2_rsrc, xsrc2[j] + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
+        } else {
+            const unsigned kb = xstep(kt);
+#pragma unroll
+            for (int j = 0; j < XI; ++j) dma16_buf(x_rsrc, xsrc[j] + kb, base + (unsigned)(wave * (BM / NW) + j * 8) * 128u);
+        }
     };
     auto issue_w = [&](int kt, int st) {
-        const bool second = kt >= k1;
-        const unsigned kb = (unsigned)(second ? kt - k1 : kt) * 128u, base = lds0 + (unsigned)st * STAGE;
-        const u32x4 rs = second ? w2_rsrc : w_rsrc;
+        const unsigned base = lds0 + (unsigned)st * STAGE;
+        if (kt >= k1) {
+            const unsigned kb = (unsigned)(kt - k1) * 128u;
 #pragma unroll
-        for (int j = 0; j < WI; ++j) dma16_buf(rs, (second ? wsrc2[j] : wsrc[j]) + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
+            for (int j = 0; j < WI; ++j) dma16_buf(w2_rsrc, wsrc2[j] + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
+        } else {
+            const unsigned kb = (unsigned)kt * 128u;
+#pragma unroll
+            for (int j = 0; j < WI; ++j) dma16_buf(w_rsrc, wsrc[j] + kb, base + XB + (unsigned)(wave * (BN / NW) + j * 8) * 128u);
+        }
     };
 
     // fragment reads: lane (i16, kq) reads row i16 of a 16-row fragment, source slot kq (hi) / 4 + kq (lo) -> position slot ^ (i16 >> 1)
@@ -133,6 +179,17 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     constexpr bool NOREAD = (ABL & 2) != 0, NODMA = (ABL & 1) != 0;
     constexpr int HM = WTM >= 4 ? WTM / 2 : WTM;         // activation fragments held at a time
     auto mfmas = [&](int h, const h16x8 (&wh)[WTN], const h16x8 (&wl)[WTN], const h16x8 (&xh)[HM], const h16x8 (&xl)[HM]) {
+        if constexpr (FMT != 0) {      // 16-bit rows: "h" = k 0..31, "l" = k 32..63 of the step, one product each
+#pragma unroll
+            for (int a = 0; a < HM; ++a)
+#pragma unroll
+                for (int c = 0; c < WTN; ++c) acc[h * HM + a][c] = mfma16<FMT>(wh[c], xh[a], acc[h * HM + a][c]);
+#pragma unroll
+            for (int a = 0; a < HM; ++a)
+#pragma unroll
+                for (int c = 0; c < WTN; ++c) acc[h * HM + a][c] = mfma16<FMT>(wl[c], xl[a], acc[h * HM + a][c]);
+            return;
+        }
 #pragma unroll
         for (int a = 0; a < HM; ++a)
 #pragma unroll
@@ -183,7 +240,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
         }
     };
 
-    const int nk = k1 + (p.K2 >> 5);
+    const int nk = k1 + (int)(ld2 >> 7);
     issue_x(0, 0);
     issue_w(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -265,9 +322,26 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
     }
 
     // epilogue: D[n][m]: lane (i16, kq) of fragment (a, c) holds channels n..n+3 (n = 16c + 4kq) of row m = 16a + i16
-    float *__restrict__ C = p.C + (size_t)b * p.c_bs;
     const bool prelu = p.act == ARSEG_ACT_PRELU, relu = p.act == ARSEG_ACT_RELU, sigm = p.act == ARSEG_ACT_SIGMOID;
     float vmax = 0.f;
+    // this lane's rows: where each goes (orow < 0: nowhere) and whether it is a pixel of the image (implicit 3x3: border rows of the padded
+    // geometry are computed like any other and then dropped or zeroed)
+    int orow[WTM], urow[WTM];         // output row; row of the unpadded NHWC image (a plain residual lives there), -1: none
+    unsigned border = 0u;             // bit a: row a is a border pixel of the padded geometry
+#pragma unroll
+    for (int a = 0; a < WTM; ++a) {
+        const int m = m0 + wm * (BM / NWM) + a * 16 + i16;
+        orow[a] = urow[a] = m < p.M ? m : -1;
+        if (p.out_mode != 0 && m < p.M) {
+            const unsigned per = (unsigned)(p.pH * p.pW), img = (unsigned)m / per, r = (unsigned)m - img * per, yp = r / (unsigned)p.pW, xp = r - yp * (unsigned)p.pW;
+            const int y = (int)yp - p.pad, x = (int)xp - p.pad;
+            const bool in = (unsigned)y < (unsigned)p.iH && (unsigned)x < (unsigned)p.iW;
+            if (!in) border |= 1u << a;
+            urow[a] = in ? ((int)img * p.iH + y) * p.iW + x : -1;
+            if (p.out_mode == 1) orow[a] = urow[a];
+        }
+    }
+    unsigned char *__restrict__ Cb = reinterpret_cast<unsigned char *>(p.C) + (size_t)b * p.c_bs * (FMT == 0 ? 4 : 2);
 #pragma unroll
     for (int c = 0; c < WTN; ++c) {
         const int n = n0 + wn * (BN / NWN) + c * 16 + 4 * kq;
@@ -277,27 +351,49 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm_x3_kernel(const GX3Params
         if (p.bias) bi = *reinterpret_cast<const f32x4 *>(p.bias + n);
 #pragma unroll
         for (int a = 0; a < WTM; ++a) {
+            if (orow[a] < 0) continue;
             const int m = m0 + wm * (BM / NWM) + a * 16 + i16;
-            if (m >= p.M) continue;
             f32x4 v = acc[a][c] * sc + bi;
-            if (p.res) v += *reinterpret_cast<const f32x4 *>(p.res + (size_t)m * p.res_ld + n);
+            if constexpr (FMT == 0) {
+                if (p.res && urow[a] >= 0) v += *reinterpret_cast<const f32x4 *>(p.res + (size_t)urow[a] * p.res_ld + n);
+                if (p.res_rows) {          // split rows [M][N]: 4 hi halves + 4 lo halves of this lane's channels
+                    const unsigned char *r = p.res_rows + ((size_t)m * p.N) * 4 + (n >> 5) * 128 + (n & 31) * 2;
+                    const uint2 h = *reinterpret_cast<const uint2 *>(r), l = *reinterpret_cast<const uint2 *>(r + 64);
+                    const h16x2 h0 = __builtin_bit_cast(h16x2, h.x), h1 = __builtin_bit_cast(h16x2, h.y), l0 = __builtin_bit_cast(h16x2, l.x), l1 = __builtin_bit_cast(h16x2, l.y);
+                    v[0] += (float)h0[0] + (float)l0[0]; v[1] += (float)h0[1] + (float)l0[1];
+                    v[2] += (float)h1[0] + (float)l1[0]; v[3] += (float)h1[1] + (float)l1[1];
+                }
+            } else {
+                const uint16_t *r16 = p.res_rows ? reinterpret_cast<const uint16_t *>(p.res_rows) + (size_t)m * p.N + n
+                                                 : (p.res && urow[a] >= 0 ? reinterpret_cast<const uint16_t *>(p.res) + (size_t)urow[a] * p.res_ld + n : nullptr);
+                if (r16) {
+                    const uint2 rv = *reinterpret_cast<const uint2 *>(r16);
+                    v[0] += arseg_h2f<FMT == 2>((uint16_t)(rv.x & 0xffffu)); v[1] += arseg_h2f<FMT == 2>((uint16_t)(rv.x >> 16));
+                    v[2] += arseg_h2f<FMT == 2>((uint16_t)(rv.y & 0xffffu)); v[3] += arseg_h2f<FMT == 2>((uint16_t)(rv.y >> 16));
+                }
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (relu) v[e] = fmaxf(v[e], 0.f);
                 else if (prelu) v[e] = v[e] >= 0.f ? v[e] : v[e] * p.slope;
                 else if (sigm) v[e] = 1.0f / (1.0f + __expf(-v[e]));
             }
-            if (p.out_split) {            // the output is the next GEMM's activation operand: written as split rows (ldc == N, N % 32 == 0)
+            if ((border >> a) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};          // (out_mode 2) the zero border of the next conv's operand
+            if constexpr (FMT != 0) {
+                const uint2 o = {(unsigned)arseg_f2h<FMT == 2>(v[0]) | ((unsigned)arseg_f2h<FMT == 2>(v[1]) << 16),
+                                 (unsigned)arseg_f2h<FMT == 2>(v[2]) | ((unsigned)arseg_f2h<FMT == 2>(v[3]) << 16)};
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(Cb) + (size_t)orow[a] * p.ldc + n) = o;
+            } else if (p.out_split) {            // the output is the next GEMM's activation operand: written as split rows (ldc == N, N % 32 == 0)
                 unsigned h01, h23, l01, l23;
                 arseg_split_f16(v, h01, h23, l01, l23);
                 vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                unsigned char *o = reinterpret_cast<unsigned char *>(C) + ((size_t)m * p.N) * 4 + (n >> 5) * 128 + (n & 31) * 2;
+                unsigned char *o = Cb + ((size_t)orow[a] * p.N) * 4 + (n >> 5) * 128 + (n & 31) * 2;
                 *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
                 *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
             } else {
                 // M / z / a 1x1 conv's output: tens of MB that the next launch streams once -- nontemporal stores (`nt`) keep them out of the
                 // 4 MB L2 of the XCD: up_2's tap GEMM (207 MB out, K = 256) 138 -> 107 us alone, +0.5 % on the step
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(C + (size_t)m * p.ldc + n));
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(Cb) + (size_t)orow[a] * p.ldc + n));
             }
         }
     }
@@ -352,30 +448,81 @@ __global__ __launch_bounds__(256) void psp_w2_split_kernel(const float *__restri
     if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
 }
 
-template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false>
+// fp32 NHWC [N][H][W][C] (row stride in_ld floats) -> zero-bordered split rows [N][H + 2 pad][W + 2 pad][C]: the activation operand of the
+// implicit 3x3 GEMM.  One thread = 4 channels of one padded pixel; border pixels are written as zeros.
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float *__restrict__ in, long long in_ld, unsigned char *__restrict__ out, int N, int H, int W, int C,
+                                                       int pad, unsigned *range_flag, float range_limit) {
+    const int c4 = C >> 2, pW = W + 2 * pad, pH = H + 2 * pad;
+    const long long total = (long long)N * pH * pW * c4;
+    float vmax = 0.f;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long px = idx / c4;
+        const int c = (int)(idx - px * c4) * 4;
+        const int xp = (int)(px % pW), yp = (int)((px / pW) % pH), n = (int)(px / ((long long)pW * pH));
+        const int y = yp - pad, x = xp - pad;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = *reinterpret_cast<const f32x4 *>(in + (((long long)n * H + y) * W + x) * in_ld + c);
+        vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+        unsigned h01, h23, l01, l23;
+        arseg_split_f16(v, h01, h23, l01, l23);
+        unsigned char *o = out + px * (long long)C * 4 + (c >> 5) * 128 + (c & 31) * 2;
+        *reinterpret_cast<uint2 *>(o) = uint2{h01, h23};
+        *reinterpret_cast<uint2 *>(o + 64) = uint2{l01, l23};
+    }
+    if (range_flag && vmax > range_limit) atomicOr(range_flag, 1u);
+}
+// the same for 16-bit NHWC tensors (8 channels = 16 bytes per thread)
+__global__ __launch_bounds__(256) void pad_rows16_kernel(const uint16_t *__restrict__ in, long long in_ld, uint16_t *__restrict__ out, int N, int H, int W, int C, int pad) {
+    const int c8 = C >> 3, pW = W + 2 * pad, pH = H + 2 * pad;
+    const long long total = (long long)N * pH * pW * c8;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long px = idx / c8;
+        const int c = (int)(idx - px * c8) * 8;
+        const int xp = (int)(px % pW), yp = (int)((px / pW) % pH), n = (int)(px / ((long long)pW * pH));
+        const int y = yp - pad, x = xp - pad;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) v = *reinterpret_cast<const uint4 *>(in + (((long long)n * H + y) * W + x) * in_ld + c);
+        *reinterpret_cast<uint4 *>(out + px * C + c) = v;
+    }
+}
+
+template <int NWM, int NWN, int WTM, int WTN, int ABL = 0, bool STAG = false, int FMT = 0>
 int launch_x3(GX3Params &p, hipStream_t hs) {
     constexpr int BM = 16 * NWM * WTM, BN = 16 * NWN * WTN;
     p.tiles_m = arseg_cdiv(p.M, BM); p.tiles_n = arseg_cdiv(p.N, BN);
     if ((long long)p.tiles_m * p.tiles_n * p.batch >= (1ll << 31)) return ARSEG_EUNSUPPORTED;
     const size_t smem = (size_t)2 * (BM + BN) * 128;
     static ArsegSmemAttr attr;
-    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG>), smem)) return e;
-    hipLaunchKernelGGL((gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG>), dim3(p.tiles_m * p.tiles_n * p.batch), dim3(64 * NWM * NWN), smem, hs, p);
+    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG, FMT>), smem)) return e;
+    hipLaunchKernelGGL((gemm_x3_kernel<NWM, NWN, WTM, WTN, ABL, STAG, FMT>), dim3(p.tiles_m * p.tiles_n * p.batch), dim3(64 * NWM * NWN), smem, hs, p);
     return arseg_launch_status();
 }
 
-template <int ABL>
+// tile_cfg -> tile shape.  0-6: the GEMM shapes of rounds 3-4; 7-10 (r5): narrow / short tiles for the implicit 3x3 convs of the 64- and 128-channel
+// layers (a 64-wide N tile cannot feed 16 waves: 8 rows of weights per DMA instruction)
+template <int ABL, int FMT>
 int launch_cfg(GX3Params &p, int cfg, hipStream_t hs) {
     switch (cfg) {
-        case 0: return launch_x3<2, 4, 8, 4, ABL>(p, hs);      // 256 x 256,  8 waves
-        case 1: return launch_x3<4, 4, 4, 4, ABL>(p, hs);      // 256 x 256, 16 waves
-        case 2: return launch_x3<2, 4, 4, 4, ABL>(p, hs);      // 128 x 256,  8 waves
-        case 3: return launch_x3<2, 4, 4, 2, ABL>(p, hs);      // 128 x 128,  8 waves
-        case 4: return launch_x3<4, 4, 4, 2, ABL>(p, hs);      // 256 x 128, 16 waves
-        case 5: return launch_x3<4, 4, 2, 4, ABL>(p, hs);      // 128 x 256, 16 waves
-        case 6: return launch_x3<4, 4, 4, 4, ABL, true>(p, hs);   // 256 x 256, 16 waves in two staggered groups
-        default: return ARSEG_EINVAL;
+        case 0: return launch_x3<2, 4, 8, 4, ABL, false, FMT>(p, hs);      // 256 x 256,  8 waves
+        case 1: return launch_x3<4, 4, 4, 4, ABL, false, FMT>(p, hs);      // 256 x 256, 16 waves
+        case 2: return launch_x3<2, 4, 4, 4, ABL, false, FMT>(p, hs);      // 128 x 256,  8 waves
+        case 3: return launch_x3<2, 4, 4, 2, ABL, false, FMT>(p, hs);      // 128 x 128,  8 waves
+        case 4: return launch_x3<4, 4, 4, 2, ABL, false, FMT>(p, hs);      // 256 x 128, 16 waves
+        case 5: return launch_x3<4, 4, 2, 4, ABL, false, FMT>(p, hs);      // 128 x 256, 16 waves
+        case 6: return launch_x3<4, 4, 4, 4, ABL, true, FMT>(p, hs);       // 256 x 256, 16 waves in two staggered groups
+        default: break;
     }
+    if constexpr (ABL == 0) {
+        switch (cfg) {
+            case 7: return launch_x3<4, 2, 4, 2, 0, false, FMT>(p, hs);    // 256 x  64,  8 waves
+            case 8: return launch_x3<4, 1, 2, 4, 0, false, FMT>(p, hs);    // 128 x  64,  4 waves (three workgroups per compute unit)
+            case 9: return launch_x3<4, 2, 2, 2, 0, false, FMT>(p, hs);    // 128 x  64,  8 waves
+            case 10: return launch_x3<2, 4, 2, 2, 0, false, FMT>(p, hs);   //  64 x 128,  8 waves
+            case 11: return launch_x3<4, 2, 2, 4, 0, false, FMT>(p, hs);   // 128 x 128,  8 waves, 32 x 64 wave tiles
+            default: break;
+        }
+    }
+    return ARSEG_EINVAL;
 }
 
 }  // namespace
@@ -431,18 +578,106 @@ static int gemm_x3(const void *x_split, const void *w_split, const void *x2_spli
     p.batch = batch; p.act = act; p.slope = prelu_slope;
     if (reinterpret_cast<uintptr_t>(range_flag) & 3) return ARSEG_EINVAL;
     p.range_flag = out_split ? reinterpret_cast<unsigned *>(range_flag) : nullptr; p.range_limit = range_limit > 0.0f ? range_limit : 65504.0f;
+    p.taps = 1; p.kg = K >> 5; p.pH = p.pW = p.iH = p.iW = 1; p.pad = 0; p.dil = 1; p.out_mode = 0; p.res_rows = nullptr; p.ldx = (unsigned)K * 4u;
     hipStream_t hs = arseg_stream(stream);
-    const int abl = tile_cfg >> 3;
-    tile_cfg &= 7;
-    switch (abl) {
-        case 0: return launch_cfg<0>(p, tile_cfg, hs);
-        case 1: return launch_cfg<1>(p, tile_cfg, hs);
-        case 2: return launch_cfg<2>(p, tile_cfg, hs);
-        case 3: return launch_cfg<3>(p, tile_cfg, hs);
-        case 4: return launch_cfg<4>(p, tile_cfg, hs);
-        default: return ARSEG_EINVAL;
+#ifdef ARSEG_GX3_ABLATE      // dev builds (tools/bench_gemm_x3.py): tile_cfg = 16 * ablation + tile; wrong results, same instruction stream otherwise
+    switch (tile_cfg >> 4) {
+        case 1: return launch_cfg<1, 0>(p, tile_cfg & 15, hs);
+        case 2: return launch_cfg<2, 0>(p, tile_cfg & 15, hs);
+        case 3: return launch_cfg<3, 0>(p, tile_cfg & 15, hs);
+        case 4: return launch_cfg<4, 0>(p, tile_cfg & 15, hs);
+        default: break;
+    }
+#endif
+    return launch_cfg<0, 0>(p, tile_cfg, hs);
+}
+
+// Implicit 3x3 conv / plain GEMM on rows of any of the three formats (fmt = enum arseg_rows_fmt); see arseg_conv3x3_rows_fwd in the header.
+static int conv_rows(const void *x_rows, const void *w_rows, void *out, int fmt, int taps, int N, int H, int W, int Cin, int Cout, int dil, int out_mode, int out_ld,
+                     const float *scale, const float *bias, const void *residual, int res_mode, int res_ld, int act, float prelu_slope, int tile_cfg,
+                     void *range_flag, float range_limit, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(x_rows); ARSEG_CHECK_PTR(w_rows); ARSEG_CHECK_PTR(out);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(Cin); ARSEG_CHECK_POS(Cout);
+    if (fmt != ARSEG_ROWS_X3 && fmt != ARSEG_ROWS_F16 && fmt != ARSEG_ROWS_BF16) return ARSEG_EINVAL;
+    if ((taps != 1 && taps != 9) || dil < 1 || dil > 8) return ARSEG_EINVAL;
+    const int eb = fmt == ARSEG_ROWS_X3 ? 4 : 2, kgran = 128 / eb;          // values per 128-byte K step
+    if (Cin % kgran) return ARSEG_EUNSUPPORTED;
+    if ((Cout & 3) || !ARSEG_ALIGNED16(x_rows) || !ARSEG_ALIGNED16(w_rows) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
+    if ((scale && !ARSEG_ALIGNED16(scale)) || (bias && !ARSEG_ALIGNED16(bias))) return ARSEG_EINVAL;
+    if (out_mode != ARSEG_ROWS_OUT_NHWC && out_mode != ARSEG_ROWS_OUT_PADDED) return ARSEG_EINVAL;
+    if (res_mode != ARSEG_ROWS_OUT_NHWC && res_mode != ARSEG_ROWS_OUT_PADDED) return ARSEG_EINVAL;
+    if (taps == 1 && (out_mode != ARSEG_ROWS_OUT_NHWC || (residual && res_mode != ARSEG_ROWS_OUT_NHWC))) return ARSEG_EINVAL;      // a 1x1 conv has no border
+    const int pad = taps == 9 ? dil : 0, pH = H + 2 * pad, pW = W + 2 * pad;
+    const long long M = (long long)N * pH * pW, K = (long long)taps * Cin;
+    if (M * Cin * eb >= (1ll << 31) || (long long)Cout * K * eb >= (1ll << 32) || M >= (1ll << 31)) return ARSEG_EUNSUPPORTED;      // 32-bit buffer offsets, "negative" tap offsets
+    const bool padded_out = out_mode == ARSEG_ROWS_OUT_PADDED;
+    // padded output = the next conv's operand in the same format: split rows need whole 32-channel groups, rows are dense
+    if (padded_out && ((fmt == ARSEG_ROWS_X3 && (Cout & 31)) || (fmt != ARSEG_ROWS_X3 && (Cout & 7)) || out_ld != Cout)) return ARSEG_EINVAL;
+    if (!padded_out && (out_ld < Cout || (out_ld & 3))) return ARSEG_EINVAL;
+    if (residual) {
+        if (!ARSEG_ALIGNED16(residual)) return ARSEG_EINVAL;
+        if (res_mode == ARSEG_ROWS_OUT_PADDED ? (res_ld != Cout || (fmt == ARSEG_ROWS_X3 && (Cout & 31))) : (res_ld < Cout || (res_ld & 3))) return ARSEG_EINVAL;
+    }
+    if (reinterpret_cast<uintptr_t>(range_flag) & 3) return ARSEG_EINVAL;
+    GX3Params p;
+    p.X = reinterpret_cast<const unsigned char *>(x_rows); p.W = reinterpret_cast<const unsigned char *>(w_rows); p.C = reinterpret_cast<float *>(out);
+    p.X2 = p.W2 = nullptr; p.K2 = 0; p.x2_bytes = p.w2_bytes = 0; p.x2_bs = p.w2_bs = 0;
+    p.scale = scale; p.bias = bias;
+    p.res = residual && res_mode == ARSEG_ROWS_OUT_NHWC ? reinterpret_cast<const float *>(residual) : nullptr;
+    p.res_rows = residual && res_mode == ARSEG_ROWS_OUT_PADDED ? reinterpret_cast<const unsigned char *>(residual) : nullptr;
+    p.res_ld = res_ld; p.out_split = padded_out && fmt == ARSEG_ROWS_X3 ? 1 : 0;
+    p.M = (int)M; p.N = Cout; p.K = (int)K; p.ldc = out_ld;
+    p.x_bytes = (unsigned)(M * Cin * eb); p.w_bytes = (unsigned)((long long)Cout * K * eb);
+    p.x_bs = p.w_bs = p.c_bs = 0; p.batch = 1; p.act = act; p.slope = prelu_slope;
+    p.range_flag = p.out_split ? reinterpret_cast<unsigned *>(range_flag) : nullptr; p.range_limit = range_limit > 0.0f ? range_limit : 65504.0f;
+    p.taps = taps; p.kg = Cin / kgran; p.pH = pH; p.pW = pW; p.pad = pad; p.dil = dil; p.iH = H; p.iW = W;
+    p.out_mode = taps == 1 ? 0 : (padded_out ? 2 : 1); p.ldx = (unsigned)Cin * eb;
+    hipStream_t hs = arseg_stream(stream);
+    switch (fmt) {
+        case ARSEG_ROWS_X3: return launch_cfg<0, 0>(p, tile_cfg, hs);
+        case ARSEG_ROWS_F16: return launch_cfg<0, 1>(p, tile_cfg, hs);
+        default: return launch_cfg<0, 2>(p, tile_cfg, hs);
     }
 }
+
+extern "C" int arseg_conv3x3_rows_fwd(const void *x_rows, const void *w_rows, void *out, int fmt, int N, int H, int W, int Cin, int Cout, int dil,
+                                      int out_mode, int out_ld, const float *scale, const float *bias, const void *residual, int res_mode, int res_ld,
+                                      int act, float prelu_slope, int tile_cfg, void *range_flag, float range_limit, arseg_stream_t stream) {
+    return conv_rows(x_rows, w_rows, out, fmt, 9, N, H, W, Cin, Cout, dil, out_mode, out_ld, scale, bias, residual, res_mode, res_ld, act, prelu_slope, tile_cfg,
+                     range_flag, range_limit, stream);
+}
+
+extern "C" int arseg_gemm_rows16_fwd(const void *x_rows, const void *w_rows, void *out, int dtype, long long M, int K, int Cout, int out_ld, const float *scale,
+                                     const float *bias, const void *residual, int res_ld, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream) {
+    if (dtype != ARSEG_DT_F16 && dtype != ARSEG_DT_BF16) return ARSEG_EINVAL;
+    if (M <= 0 || M >= (1ll << 31)) return ARSEG_EINVAL;
+    return conv_rows(x_rows, w_rows, out, dtype == ARSEG_DT_BF16 ? ARSEG_ROWS_BF16 : ARSEG_ROWS_F16, 1, 1, (int)M, 1, K, Cout, 1, ARSEG_ROWS_OUT_NHWC, out_ld, scale, bias,
+                     residual, ARSEG_ROWS_OUT_NHWC, res_ld, act, prelu_slope, tile_cfg, nullptr, 0.0f, stream);
+}
+
+extern "C" int arseg_pad_rows_fwd(const void *in, long long in_ld, void *out_rows, int fmt, int N, int H, int W, int C, int pad, void *range_flag,
+                                  float range_limit, arseg_stream_t stream) {
+    ARSEG_CHECK_PTR(in); ARSEG_CHECK_PTR(out_rows);
+    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W); ARSEG_CHECK_POS(C);
+    if (fmt != ARSEG_ROWS_X3 && fmt != ARSEG_ROWS_F16 && fmt != ARSEG_ROWS_BF16) return ARSEG_EINVAL;
+    if (pad < 0 || pad > 8 || in_ld < C || !ARSEG_ALIGNED16(in) || !ARSEG_ALIGNED16(out_rows) || (reinterpret_cast<uintptr_t>(range_flag) & 3)) return ARSEG_EINVAL;
+    const long long px = (long long)N * (H + 2 * pad) * (W + 2 * pad);
+    hipStream_t hs = arseg_stream(stream);
+    if (fmt == ARSEG_ROWS_X3) {
+        if ((C & 31) || (in_ld & 3)) return ARSEG_EINVAL;
+        long long blocks = (px * (C >> 2) + 255) / 256;
+        hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, hs, reinterpret_cast<const float *>(in), in_ld,
+                           reinterpret_cast<unsigned char *>(out_rows), N, H, W, C, pad, reinterpret_cast<unsigned *>(range_flag), range_limit > 0.0f ? range_limit : 65504.0f);
+    } else {
+        if ((C & 7) || (in_ld & 7)) return ARSEG_EINVAL;
+        long long blocks = (px * (C >> 3) + 255) / 256;
+        hipLaunchKernelGGL(pad_rows16_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, hs, reinterpret_cast<const uint16_t *>(in), in_ld,
+                           reinterpret_cast<uint16_t *>(out_rows), N, H, W, C, pad);
+    }
+    return arseg_launch_status();
+}
+
+
 
 extern "C" int arseg_gemm_x3_fwd(const void *x_split, const void *w_split, float *out, int M, int N, int K, int out_ld, int batch,
                                  long long x_batch_stride, long long w_batch_stride, long long out_batch_stride, const float *scale,
