@@ -76,7 +76,7 @@ def rows_eligible(pc, cin: int, fmt: int) -> bool:
     return pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == pc.dil and 1 <= pc.dil <= 8 and cin % gran == 0 and pc.cout % 4 == 0
 
 
-def pad_rows(x: torch.Tensor, pad: int) -> PaddedRows:
+def pad_rows(x: torch.Tensor, pad: int, record: bool = True) -> PaddedRows:
     """NHWC tensor (fp32, or fp16 / bf16 on the 16-bit path; may be a channel slice) -> PaddedRows with a zero border of ``pad`` pixels: one
     memory-bound pass (arseg_pad_rows_fwd); for split rows it carries the operand range watch of the conv that will read it."""
     n, h, w, c = x.shape
@@ -88,7 +88,11 @@ def pad_rows(x: torch.Tensor, pad: int) -> PaddedRows:
         _need_gpu(x)
         t = torch.empty((n, h + 2 * pad, w + 2 * pad, c), dtype=torch.float32, device=x.device)
         fmt, rw = _lib.ROWS_X3, (_range_word(x.device) if sw.RANGE_MODE == "device" else None)
-    launch("pad_rows", _lib.load().arseg_pad_rows_fwd, _ptr(x), _nhwc_ld(x), _ptr(t), fmt, n, h, w, c, pad, _ptr(rw), 65504.0, _stream())
+    args = (_ptr(x), _nhwc_ld(x), _ptr(t), fmt, n, h, w, c, pad, _ptr(rw), 65504.0, _stream())
+    if record:
+        launch("pad_rows", _lib.load().arseg_pad_rows_fwd, *args)
+    else:
+        check(_lib.load().arseg_pad_rows_fwd(*args), "pad_rows")
     return PaddedRows(t, pad)
 
 
@@ -171,6 +175,53 @@ def conv3x3_rows(x: PaddedRows, pc, residual=None, out_padded: bool = False, out
     with tagged(lambda: (n, h, w, pc.cin, cout, 3, 1, pc.dil, False, f"rows3({cfg})", flops)):
         run(cfg, record)
     return PaddedRows(o, x.pad) if out_padded else o
+
+
+def gemm_rows16(x: torch.Tensor, pc, residual=None, out: Optional[torch.Tensor] = None, cfg: Optional[int] = None, record: bool = True):
+    """1x1 stride-1 conv of the 16-bit storage path as a plain GEMM of the LDS-DMA kernel (arseg_gemm_rows16_fwd): x NHWC fp16 / bf16 with dense
+    rows (Cin % 64 == 0), 16-bit output (may be a channel slice).  cfg None: the tile shape is timed on first use per (M, K, N)."""
+    lib = _lib.load()
+    dt = _need_gpu16(x, residual, out)
+    n, h, w, cin = x.shape
+    w16, cin16 = pc.weights16(x.dtype)
+    if cin != cin16 or cin % 64 or _nhwc_ld(x) != cin or pc.R != 1 or pc.S != 1 or pc.stride != 1 or pc.pad != 0 or pc.cout % 4:
+        raise _lib.ArsegError("gemm_rows16: a 1x1 stride-1 conv on dense 16-bit rows with Cin % 64 == 0 and Cout % 4 == 0 is required")
+    M, cout = n * h * w, pc.cout
+    if out is None:
+        out = torch.empty((n, h, w, (cout + 7) // 8 * 8), dtype=x.dtype, device=x.device)[..., :cout]
+    elif tuple(out.shape) != (n, h, w, cout):
+        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(n, h, w, cout)}")
+    if residual is not None and tuple(residual.shape) != (n, h, w, cout):
+        raise _lib.ArsegError("residual shape mismatch")
+    flops = 2 * M * cin * cout
+
+    def run(c, rec):
+        args = (_ptr(x), _ptr(w16), _ptr(out), dt, M, cin, cout, _nhwc_ld(out), _ptr(pc.scale), _ptr(pc.bias), _ptr(residual),
+                _nhwc_ld(residual) if residual is not None else 0, pc.act, pc.slope, c, _stream())
+        if rec:
+            launch("conv2d", lib.arseg_gemm_rows16_fwd, *args, flops=flops)
+        else:
+            check(lib.arseg_gemm_rows16_fwd(*args), "gemm_rows16")
+
+    if cfg is None:
+        key = ("gemm16", x.device.index, dt, M, cin, cout, residual is not None)
+        cfg = _conv_plans.get(key)
+        if cfg is None:
+            if not sw.AUTOTUNE or torch.cuda.is_current_stream_capturing():
+                cfg = 9 if cout <= 64 else 3
+            else:
+                best_t = float("inf")
+                for c in _ROWS_CFGS:
+                    try:
+                        tm = _time(lambda: run(c, False))
+                    except _lib.ArsegError:
+                        continue
+                    if tm < best_t:
+                        cfg, best_t = c, tm
+                _conv_plans[key] = cfg
+    with tagged(lambda: (n, h, w, pc.cin, cout, 1, 1, 1, False, f"gemm16({cfg})", flops)):
+        run(cfg, record)
+    return out
 
 
 def gemm_x3_enabled() -> bool:
@@ -352,6 +403,10 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     def launch_x3(record=True):
         _conv1x1_x3(x, pc, residual, out, False, None, record)
 
+    def launch_rows(record=True):
+        # pad pass + implicit 3x3 GEMM of the LDS-DMA kernel (conv3x3_rows); a conv -> conv chain that stays in padded rows skips the pass
+        conv3x3_rows(pad_rows(x, pc.dil, record=record), pc, residual, out=out, record=record)
+
     def find_native():
         """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
         fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
@@ -375,8 +430,10 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         taps_ok = (x_low is not None and sw.UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
                    and pc.dil == 1 and pc.cout % 4 == 0)
         x3_ok = _x3_eligible(pc, Cin, residual, x_low is not None) and not wino_ok
+        rows_ok = x_low is None and igemm3_enabled() and math == _lib.MATH_F16X3 and rows_eligible(pc, Cin, _lib.ROWS_X3)
         plan = _conv_plans.get(key)
-        if (plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or plan == "tapsf":      # a persisted plan whose route is switched off / gone: re-tune
+        if ((plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or (plan == "rows" and not rows_ok)
+                or plan == "tapsf"):      # a persisted plan whose route is switched off / gone: re-tune
             plan = None
         if plan is None:
             plan = find_native() if sw.NATIVE_FIND else None
@@ -413,9 +470,17 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "x3"
                 except _lib.ArsegError:
                     pass
-            if taps_ok:
+            if rows_ok:                                         # pad pass + implicit 3x3 GEMM on the LDS-DMA kernel against the best so far
                 try:
                     t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: run_plan(*plan, record=False)))
+                    launch_rows(record=False)                   # picks its tile shape
+                    if _time(lambda: launch_rows(record=False)) < t_best:
+                        plan = "rows"
+                except _lib.ArsegError:
+                    pass
+            if taps_ok:
+                try:
+                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else ((lambda: launch_rows(record=False)) if plan == "rows" else (lambda: run_plan(*plan, record=False))))
                     launch_taps(record=False)                   # tunes the low-resolution GEMM underneath
                     if _time(lambda: launch_taps(record=False)) < t_best:
                         plan = "taps"
@@ -429,6 +494,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 launch_taps()
             elif plan == "x3":
                 launch_x3()
+            elif plan == "rows":
+                launch_rows()
             else:
                 run_plan(*plan)
     else:
@@ -493,7 +560,30 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
                         continue
                     if t < best_t:
                         plan, best_t = (cfg, sk), t
-            _conv_plans[key] = plan = plan or (0, 0)
+            plan = plan or (0, 0)
+            if igemm3_enabled(x) and pc.R == 1 and pc.S == 1 and pc.stride == 1 and pc.pad == 0 and Cin % 64 == 0 and pc.cout % 4 == 0 and d.in_ld == Cin:
+                try:                                                                       # 1x1: the plain GEMM of the LDS-DMA kernel
+                    gemm_rows16(x, pc, residual, out, record=False)
+                    if _time(lambda: gemm_rows16(x, pc, residual, out, record=False)) < best_t:
+                        plan = "gemm16"
+                except _lib.ArsegError:
+                    pass
+            if igemm3_enabled(x) and not up2 and rows_eligible(pc, Cin, _lib.ROWS_BF16):      # pad pass + implicit 3x3 GEMM on the LDS-DMA kernel
+                try:
+                    conv3x3_rows(pad_rows(x, pc.dil, record=False), pc, residual, out=out, record=False)
+                    if _time(lambda: conv3x3_rows(pad_rows(x, pc.dil, record=False), pc, residual, out=out, record=False)) < best_t:
+                        plan = "rows"
+                except _lib.ArsegError:
+                    pass
+            _conv_plans[key] = plan
+        if plan == "rows":
+            if igemm3_enabled(x) and rows_eligible(pc, Cin, _lib.ROWS_BF16):
+                return conv3x3_rows(pad_rows(x, pc.dil), pc, residual, out=out)
+            plan = (0, 0)                      # the route was switched off after the plan was cached: the library's heuristic
+        if plan == "gemm16":
+            if igemm3_enabled(x) and d.in_ld == Cin:
+                return gemm_rows16(x, pc, residual, out)
+            plan = (0, 0)
         d.tile_cfg, d.split_k = plan
     flops16 = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin
     with tagged((N, H, W, pc.cin, pc.cout, pc.R, pc.stride, pc.dil, bool(up2), "16-bit " + str((d.tile_cfg, d.split_k)), flops16)):      # per-layer table (profile.layers())

@@ -391,6 +391,34 @@ def test_conv3x3_rows_block_chain(dev, storage):
     assert z.dtype == sdt and maxdiff(z.float(), y.float()) <= (1e-4 if storage == "x3" else 2.5e-2 * scale)
 
 
+@pytest.mark.parametrize("storage", ["f16", "bf16"])
+def test_gemm_rows16(dev, storage):
+    """arseg_gemm_rows16_fwd: the 1x1 convs of the 16-bit storage path (bisenet.py FFM / SpatialPath / ARM heads) on the LDS-DMA kernel -- every
+    tile shape, with BN, bias, residual and ReLU, the output a channel slice -- against the same product of the rounded operands in fp64; and
+    ops.conv2d picks whichever of this and the conv16 kernel is faster without changing the result beyond the output rounding."""
+    from arseg_amd import _lib, ops
+    from arseg_amd.packing import PackedConv
+
+    sdt = {"f16": torch.float16, "bf16": torch.bfloat16}[storage]
+    N, H, W, Cin, Cout = 2, 9, 13, 128, 96
+    g = np.random.Generator(np.random.PCG64(171))
+    x = rnd(170, N, H, W, Cin).to(sdt)
+    w = rnd(172, Cout, Cin, 1, 1, scale=0.1)
+    bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(174, Cout, scale=0.1), rnd(175, Cout, scale=0.1), t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
+    res = rnd(176, N, H, W, Cout).to(sdt)
+    pc = PackedConv(w, None, bn, 1, 0, 1, _lib.ACT_RELU, 0.0, dev)
+    want = _conv_ref(x.double().permute(0, 3, 1, 2), w.to(sdt).double(), None, tuple(v.double() for v in bn), 1, 0, 1, "relu", 0.0, res.double().permute(0, 3, 1, 2))
+    tol = float(want.abs().max()) * {"f16": 1.5e-3, "bf16": 1.2e-2}[storage]
+    xd, rd = x.to(dev), res.to(dev)
+    for cfg in range(12):
+        wide = torch.zeros((N, H, W, Cout + 16), dtype=sdt, device=dev)
+        ops.gemm_rows16(xd, pc, residual=rd, out=wide[..., 8:8 + Cout], cfg=cfg)
+        assert maxdiff(wide[..., 8:8 + Cout].float().permute(0, 3, 1, 2), want) <= tol, cfg
+        assert float(wide[..., :8].abs().max()) == 0 and float(wide[..., 8 + Cout:].abs().max()) == 0
+    got = ops.conv2d(xd, pc, residual=rd)
+    assert got.dtype == sdt and maxdiff(got.float().permute(0, 3, 1, 2), want) <= tol
+
+
 def test_conv2d_channel_slices(dev, conv_math):
     """in_ld / out_ld: read a channel slice of a wider NHWC buffer and write into one (zero-copy concat)."""
     from arseg_amd import _lib, ops
@@ -758,13 +786,13 @@ def test_gemm_x3(dev, B, M, K, N):
     ref = torch.bmm(x.double(), w.double().transpose(1, 2))
     for act, slope in ((_lib.ACT_NONE, 0.0), (_lib.ACT_PRELU, 0.25)):
         want = ref if act == _lib.ACT_NONE else F.prelu(ref * scale.double() + bias.double(), torch.tensor([slope], dtype=torch.float64, device=dev))
-        for cfg in range(7):
+        for cfg in range(12):          # 0-6: the GEMM tiles of rounds 3-4, 7-11: the narrow tiles added for the implicit 3x3 convs (r5)
             out = torch.full((B, M, N), float("nan"), device=dev)
             sb = (None, None) if act == _lib.ACT_NONE else (scale, bias)
             _lib.check(lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, M * K * 4, N * K * 4, M * N, P(sb[0]), P(sb[1]), None, 0, act, slope, 0, cfg, None, 0.0, st), "gemm_x3")
             assert float((out.double() - want).abs().max()) <= 3e-6 * float(want.abs().max()), (act, cfg)
     assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K + 1, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 0, None, 0.0, st) == _lib.ARSEG_EINVAL
-    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 7, None, 0.0, st) == _lib.ARSEG_EINVAL
+    assert lib.arseg_gemm_x3_fwd(P(xs), P(ws), P(out), M, N, K, N, B, 0, 0, 0, None, None, None, 0, 0, 0.0, 0, 12, None, 0.0, st) == _lib.ARSEG_EINVAL
 
 
 @pytest.mark.parametrize("N,h,w,Cin,Cout", [(2, 9, 13, 64, 64), (1, 16, 32, 256, 64), (1, 1, 1, 64, 32), (3, 33, 70, 64, 128), (2, 7, 40, 64, 64)])

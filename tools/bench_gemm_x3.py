@@ -53,7 +53,7 @@ def main():
     ap.add_argument("--json")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", type=int, default=-1)
-    ap.add_argument("--cfgs", default="0,1,2,3,4,5,6", help="tile_cfg values of the new kernel (4 + c / 8 + c / 12 + c, c in {0, 3}: ablation builds without DMA / fragment reads / both; wrong results)")
+    ap.add_argument("--cfgs", default="0,1,2,3,4,5,6", help="tile_cfg values of the new kernel (0-11).  Ablation builds: compile csrc/gemm_x3.hip with -DARSEG_GX3_ABLATE and pass 16 * a + c (a = 1: no DMA, 2: no fragment reads, 3: neither, 4: raised MFMA priority; wrong results, same instruction stream otherwise)")
     args = ap.parse_args()
     global CFGS
     CFGS = [int(c) for c in args.cfgs.split(",")]
