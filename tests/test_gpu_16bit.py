@@ -308,3 +308,60 @@ def test_frame_ingest_16bit_equals_rounded_fp32(dev, dtype, H, W, h, w):
     assert bool(((got[..., :3].float() - ref[..., :3]).abs() <= ulp * ref[..., :3].abs() + 1e-7).all())
     assert float((got[..., :3].float() != ref[..., :3].to(dtype).float()).float().mean()) < 1e-3      # (and nearly always the same rounding)
     assert float(got[..., 3:].float().abs().max()) == 0.0
+
+
+# Full-size bounds (the bench variants' max_abs_err moved 0.035 <-> 0.30 between runs with no test bounding it).  Measured on MI355X,
+# round 5, over both plan sets the tuner produces (bounds = ~2x the worst measurement; the fp32 oracle's logits span about +-20):
+#   max_abs = worst pixel of the x8-upsampled logits; rms = whole-map RMS error relative to the RMS of the oracle's logits; agree = label agreement
+#   bf16 (0.5x): max_abs 0.33 (logits) / 0.26 (keyframe feature), rms 0.80 % / 0.79 %, agreement 0.9930 (bench clip: 0.9949-0.9956, max_abs 0.26-0.30)
+#   fp16 (0.3x): max_abs 0.033 / 0.035, rms 0.088 % / 0.091 %, agreement 0.99945 -- the "0.035" of the round-4 records is this configuration's number
+FULL16 = {
+    # storage: (scale, max_abs bound, relative rms bound, label agreement bound)
+    "bf16": (0.5, 0.70, 1.8e-2, 0.985),
+    "f16": (0.3, 0.08, 2.0e-3, 0.998),
+}
+
+
+@pytest.mark.parametrize("storage", ["bf16", "f16"])
+def test_full_size_16bit_step(dev, storage):
+    """BASELINE configs[2] (bf16, LR 0.5x) and configs[4] (fp16, LR 0.3x = 307x614) at FULL size inside the suite (model/bisenet.py:546-575 at
+    1024x2048): BiSeNet-18 keyframe HR forward + one non-keyframe through downscale -> LR backbone -> MV warp + CReFF (C = 256 at 128x256) + head,
+    16-bit activations and weights, against the fp32 CPU oracle.  16-bit storage is reduced precision by construction, so the bounds are stated
+    (FULL16) instead of 1e-3: worst pixel, relative RMS and label agreement of the logits, and the same for the keyframe feature; the fused
+    argmax tail must agree with the argmax of the logits it never writes.  The odd LR size of configs[4] (307x614 -> 39x77 / 40x78 maps) is the
+    path the reference re-interpolates on (bisenet.py:298,442)."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+    from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse
+    from oracle import cpu_ref
+    import os
+
+    scale, b_max, b_rms, b_agree = FULL16[storage]
+    sdt = {"bf16": torch.bfloat16, "f16": torch.float16}[storage]
+    H, W = 1024, 2048
+    hr, lr = BiSeNetV1(n_classes=19, backend="resnet18"), BiSeNetV1WithFuse(n_classes=19, backend="resnet18")
+    synth.load_synth_weights(hr, 0)
+    synth.load_synth_weights(lr, 1)
+    sd_hr = synth.resolve_aliases({k: v.clone() for k, v in hr.state_dict().items()})
+    sd_lr = synth.resolve_aliases({k: v.clone() for k, v in lr.state_dict().items()})
+    hr, lr = hr.to(dev).eval().set_storage(sdt), lr.to(dev).eval().set_storage(sdt)
+    clip = synth.make_clip(0, H, W, gop=4, mean=synth.CITY_BISE_MEAN, std=synth.CITY_BISE_STD)
+    key, img, mvq = (torch.from_numpy(clip[k][i:i + 1]) for k, i in (("frames", 0), ("frames", 3), ("mv", 3)))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        o_out, o_p, _, o_ref = cpu_ref.alter_res_step("bise", sd_hr, sd_lr, img, key, cpu_ref.mv_from_int16(mvq), scale)
+        ref_p = hr(key.to(dev))[-1]
+        out, _ = ev.alter_res_step_fast(lr, ops.to_nhwc(ref_p), img.to(dev), mvq.to(dev), scale)
+        pred, _ = ev.alter_res_batch_pred(lr, [ops.to_nhwc(ref_p)[0]], img.to(dev), mvq.to(dev), scale)
+    out, ref = out.float().cpu(), ref_p.float().cpu()
+    stats = {"max_abs_logits": float((out - o_out).abs().max()), "rms_rel_logits": float((out - o_out).pow(2).mean().sqrt() / o_out.pow(2).mean().sqrt()),
+             "max_abs_ref": float((ref - o_ref).abs().max()), "rms_rel_ref": float((ref - o_ref).pow(2).mean().sqrt() / o_ref.pow(2).mean().sqrt()),
+             "agree": float((out.argmax(1) == o_out.argmax(1)).float().mean()), "agree_fused_tail": float((pred.cpu().long() == o_out.argmax(1)).float().mean()),
+             "logit_span": float(o_out.abs().max()), "ref_span": float(o_ref.abs().max())}
+    print("FULL16", storage, stats)
+    assert stats["max_abs_logits"] <= b_max and stats["rms_rel_logits"] <= b_rms and stats["agree"] >= b_agree, stats
+    assert stats["rms_rel_ref"] <= b_rms and stats["max_abs_ref"] <= b_max, stats
+    assert stats["agree_fused_tail"] >= b_agree, stats
+    # the fused tail computes the argmax of exactly the logits the un-fused path writes (same kernels up to the head): near-ties aside, identical
+    same = float((pred.cpu().long() == out.argmax(1)).float().mean())
+    assert same >= 0.9995, same
