@@ -103,8 +103,20 @@ __device__ __forceinline__ void store4_buf(unsigned v, const u32x4 rsrc, unsigne
 }
 __device__ __forceinline__ unsigned lds_addr(const void *p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void *)p; }
 
+#ifdef MFMA_TIMING
+// dev builds only (tools/time_mfma.py): every wave adds the shader-clock ticks since its previous stamp to its row of a device-global table
+__device__ unsigned long long g_mfma_dbg[16 * 16];
+#define MF_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tacc_[i] += now_ - tprev_; tprev_ = now_; } while (0)
+#else
+#define MF_STAMP(i) do { } while (0)
+#endif
+
 template <int NB, int TY>      // NB: classifier row blocks of 16 classes (0: no head)
 __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParams p) {
+#ifdef MFMA_TIMING
+    unsigned long long tacc_[15] = {};          // (wave uniform: scalar registers; flushed once per tile at the end of the kernel)
+    unsigned long long tprev_ = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int NBA = NB > 0 ? NB : 1;
     typedef Geo<TY> GE;
     constexpr int NT = GE::NT, HBUF = GE::HBUF, RH = GE::RH, HH = GE::HH, LH = GE::LH, KPLK = GE::KPLK, KPLV = GE::KPLV, HPL = GE::HPL, LPL = GE::LPL;
@@ -170,18 +182,23 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     };
 
     // Per-thread work items of the staging / convolution rounds do not depend on the channel chunk: decode them once.
-    constexpr int H_TOT = G * HH * HWD, H_NI = (H_TOT + NT - 1) / NT;
-    constexpr int K_TOT = G * RH * RWC, K_NI = (K_TOT + NT - 1) / NT;
+    // Hs layout (r5): [row][channel group][column] -- a staged row is G * HWD = 104 consecutive slots, i.e. two LDS-DMA instructions whose source
+    // offsets are a lane constant plus scalars (issue_hr).  Key / value conv items: one thread = channel group, TWO vertically adjacent record rows,
+    // one record column -- the 4 x 3 input window is read once for both outputs and so are the ten weight vectors (22 LDS reads per two outputs
+    // instead of 38: the conv was bound by its LDS reads, profiles/r05_creff_mfma_phases_before.json)
+    constexpr int HROW = G * HWD;
+    static_assert(RH % 2 == 0, "record rows come in pairs");
+    constexpr int K_TOT = G * (RH / 2) * RWC, K_NI = (K_TOT + NT - 1) / NT;
     constexpr int L_TOT = G * LH * LWD, L_NI = (L_TOT + NT - 1) / NT;
     constexpr unsigned BAD = 0x80000000u;             // beyond num_records even after the chunk offset is added
-    int kh[K_NI], kk[K_NI], kg[K_NI];                  // Hs read index, Kl write index, channel group
-    bool kin[K_NI];
+    int kcode[K_NI];          // one register per item: row | column << 8 | group << 16 | upper output inside the image << 20 | lower << 21
 #pragma unroll
     for (int it = 0; it < K_NI; ++it) {
         const int i = min(tid + it * NT, K_TOT - 1);   // surplus lanes of the last round redo the last item
-        const int gg = i / (RH * RWC), rem = i - gg * (RH * RWC), r = rem / RWC, c = rem - r * RWC;
-        kh[it] = gg * HPL + r * HWD + c; kk[it] = r * RW + c; kg[it] = gg;
-        kin[it] = (unsigned)(ty0 - 3 + r) < (unsigned)p.Hp && (unsigned)(tx0 - 3 + c) < (unsigned)p.Wp;
+        const int gg = i / ((RH / 2) * RWC), rem = i - gg * ((RH / 2) * RWC), rp = rem / RWC, c = rem - rp * RWC, r = 2 * rp;
+        const bool cin = (unsigned)(tx0 - 3 + c) < (unsigned)p.Wp;
+        const int in0 = cin && (unsigned)(ty0 - 3 + r) < (unsigned)p.Hp, in1 = cin && (unsigned)(ty0 - 2 + r) < (unsigned)p.Hp;
+        kcode[it] = r | (c << 8) | (gg << 16) | (in0 << 20) | (in1 << 21);
     }
     int lrc_[L_NI];                                    // lr_up tile items: row | col << 8 | group << 16, -1 = none
 #pragma unroll
@@ -191,7 +208,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         lrc_[it] = i < L_TOT ? (r | (c << 8) | (gg << 16)) : -1;
     }
     const u32x4 h_rsrc = make_rsrc(p.hr + (size_t)n * p.C * p.Hp * p.Wp, (unsigned)((size_t)p.C * p.Hp * p.Wp * sizeof(float)));
-    const unsigned h_chunk = (unsigned)(2 * p.Hp * p.Wp * 8) * 4u;      // bytes between 16-channel chunks (C8 layout)
+    const unsigned h_chunk = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(2 * p.Hp * p.Wp * 8) * 4u));      // bytes between 16-channel chunks (C8 layout); pinned to an SGPR (as a VGPR it was spilled and reloaded between the DMA requests)
 
     // Staging is asynchronous: the next chunk's hr region, lr window and depthwise weights go global -> LDS directly
     // (LDS-DMA, no staging registers) into the other half of double buffers while the current chunk is convolved and
@@ -199,21 +216,32 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     // carry an out-of-range buffer offset and arrive as zeros (the conv's zero padding).
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int lw_tot = G * ly_n * lx_n;
+    // exact for dividends below 2^16 (here < 2048): floor(2^32 / d) + 1
+    const unsigned m_npx = (unsigned)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / (unsigned)(ly_n * lx_n) + 1u));
+    const unsigned m_lxn = (unsigned)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / (unsigned)lx_n + 1u));
     f32x4 pf_w;
+    // (measured and dropped in r5: the next chunk's requests spread over the iteration -- one behind barrier A, the rest between the VALU phases --
+    // instead of a burst behind the barrier: the address arithmetic then lives across the convs, 100+ bytes of scratch, 72.7 -> 90.4 us per frame)
     auto issue_hr = [&](int k, int buf) {
         // the offsets are decoded again per chunk from an opaque thread id: kept in registers across the chunk loops they were spilled,
         // and every reload from scratch waited (vmcnt(0)) for the DMA issued just before it -- three serialised round trips per chunk
-        int t_ = tid; asm volatile("" : "+v"(t_));
+        // (r5) one instruction = 64 (or the last 40) consecutive slots of one staged row: slot s = (group, column) is a LANE constant, the row and
+        // the chunk are scalars -- ~10 VALU per instruction where the per-item decode of rounds 1-4 took ~25 for each of three (the DMA issue was
+        // 16 % of pass 1 and the pole wave's longest phase).  Lanes beyond the row's 104 slots are masked off (they would zero the next row).
+        // (the lane id comes from mbcnt, two instructions: any copy of it that lives across the chunk loops ends up in scratch, and a scratch reload
+        // between two DMA requests waits for the first one)
+        int l_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l_));
+        constexpr int PER_W = (HH * 2) / (NT / 64);          // instructions per wave: 3 (16-row tiles) / 4 (8-row tiles)
+        static_assert(PER_W * (NT / 64) == HH * 2, "rows x 2 must divide over the waves");
 #pragma unroll
-        for (int it = 0; it < H_NI; ++it)
-            if (it * NT + wave_u * 64 < H_TOT) {
-                const int i = t_ + it * NT;
-                const int gg = i / HPL, px = i - gg * HPL, r = px / HWD, c = px - r * HWD;
-                const int gy = ty0 - 4 + r, gx = tx0 - 4 + c;
-                const bool ok = i < H_TOT && (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
-                const unsigned ho = ok ? (unsigned)((((gg >> 1) * p.Hp + gy) * p.Wp + gx) * 8 + (gg & 1) * 4) * 4u : BAD;
-                dma16_buf(h_rsrc, ho + k * h_chunk, lds_addr(Hs + (HBUF == 2 ? buf : 0) * G * HPL + it * NT + wave_u * 64));
-            }
+        for (int j = 0; j < PER_W; ++j) {
+            const int ins = wave_u * PER_W + j, r = ins >> 1, h = ins & 1;      // (scalar)
+            const int sl = 64 * h + l_, gg = sl / HWD, c = sl - gg * HWD;
+            const int gy = ty0 - 4 + r, gx = tx0 - 4 + c;
+            const bool ok = (unsigned)gy < (unsigned)p.Hp && (unsigned)gx < (unsigned)p.Wp;
+            const unsigned ho = ok ? (unsigned)((((gg >> 1) * p.Hp + gy) * p.Wp + gx) * 8 + (gg & 1) * 4) * 4u : BAD;
+            if (sl < HROW) dma16_buf(h_rsrc, ho + (unsigned)__builtin_amdgcn_readfirstlane((int)(k * h_chunk)), lds_addr(Hs + (HBUF == 2 ? buf : 0) * G * HPL + r * HROW + 64 * h));
+        }
     };
     auto issue = [&](int k, int buf, bool head) {
         if (HBUF == 2) issue_hr(k, buf);           // double buffered: nobody reads the other half now
@@ -223,7 +251,9 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         int tid = tid_; asm volatile("" : "+v"(tid));
         if (wave_u * 64 < lw_tot) {
             const int i = min(tid, lw_tot - 1);          // surplus lanes of the last wave repeat the last item (stay inside Lw)
-            const int npx = ly_n * lx_n, gg = i / npx, px = i - gg * npx, r = px / lx_n, c = px - r * lx_n;
+            // divisions by the (uniform) window extents as multiply-high with SGPR constants: hipcc's own expansion hoists its VGPR reciprocals
+            // out of the chunk loops, where they were spilled and reloaded behind the DMA requests (r5)
+            const int npx = ly_n * lx_n, gg = (int)__umulhi((unsigned)i, m_npx), px = i - gg * npx, r = (int)__umulhi((unsigned)px, m_lxn), c = px - r * lx_n;
             const float *src = p.lr + ((size_t)n * p.hp * p.wp + (size_t)(ly_lo + r) * p.wp + lx_lo + c) * p.C + k * 16 + gg * 4;
             if (tid < lw_tot) dma16_glb(src, lds_addr(Lw + buf * LWCAP + wave_u * 64));
         }
@@ -236,7 +266,12 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
             const float *src = tp < 9 ? w + (size_t)tp * p.C + c : bb + c;
             if (tid < 3 * 10 * G) dma16_glb(src, lds_addr(Wd + buf * 3 * 10 * G + wave_u * 64));
         }
-        if (NB > 0 && head && tid < G * NBA * 16) {   // classifier slice [class][16 ch] of the chunk, entry = (group, class)
+        (void)head;
+    };
+    // classifier slice [class][16 ch] of chunk k, entry = (group, class): requested right in front of a chunk's MFMA loop and committed behind it (r5: as
+    // part of issue() the four registers were live through the whole iteration, across the convs that need every register they can get)
+    auto load_head = [&](int k) {
+        if (NB > 0 && tid < G * NBA * 16) {
             const int cls = tid % (NBA * 16), gg = tid / (NBA * 16);
             pf_w = f32x4{0.f, 0.f, 0.f, 0.f};
             if (cls < p.n_cls) pf_w = *reinterpret_cast<const f32x4 *>(p.wf + (size_t)cls * p.C + k * 16 + gg * 4);
@@ -254,17 +289,30 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         const f32x4 *w = Wd + (buf * 3 + cv) * 10 * G, *hs = Hs + (HBUF == 2 ? buf : 0) * G * HPL;
 #pragma unroll
         for (int it = 0; it < K_NI; ++it) {
-            const f32x4 *h = hs + kh[it];
-            const f32x4 *wg = w + kg[it];
-            f32x4 acc = wg[9 * G];
+            const int code = kcode[it], kr = code & 255, kc = (code >> 8) & 255, kgg = (code >> 16) & 15;
+            const f32x4 *h = hs + (kr * G + kgg) * HWD + kc;
+            const f32x4 *wg = w + kgg;
+            f32x4 a0 = wg[9 * G], a1 = a0;
+            f32x4 u0 = h[0], u1 = h[1], u2 = h[2];          // window row t (upper output's tap row t)
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) acc += wg[(dy * 3 + dx) * G] * h[dy * HWD + dx];
-            if (!kin[it]) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 3; ++t) {            // tap row t: weights read once, applied to window row t (upper) and t + 1 (lower output)
+                const f32x4 v0 = h[(t + 1) * HROW], v1 = h[(t + 1) * HROW + 1], v2 = h[(t + 1) * HROW + 2];
+                { const f32x4 w0 = wg[(t * 3) * G]; a0 += w0 * u0; a1 += w0 * v0; }
+                __builtin_amdgcn_sched_barrier(0);
+                { const f32x4 w1 = wg[(t * 3 + 1) * G]; a0 += w1 * u1; a1 += w1 * v1; }
+                __builtin_amdgcn_sched_barrier(0);
+                { const f32x4 w2 = wg[(t * 3 + 2) * G]; a0 += w2 * u2; a1 += w2 * v2; }
+                u0 = v0; u1 = v1; u2 = v2;
+                __builtin_amdgcn_sched_barrier(0);      // keep the live set at two window rows + one weight row (all twelve loads hoisted: spills)
+            }
+            if (!(code & (1 << 20))) a0 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (!(code & (1 << 21))) a1 = f32x4{0.f, 0.f, 0.f, 0.f};
             u32x2 hi, lo;
-            split4(acc, hi, lo);
-            Kl[kk[it] + kg[it] * (cv == 1 ? KPLK : KPLV)] = u32x4{hi.x, hi.y, lo.x, lo.y};
+            u32x4 *dst = Kl + kr * RW + kc + kgg * (cv == 1 ? KPLK : KPLV);
+            split4(a0, hi, lo);
+            dst[0] = u32x4{hi.x, hi.y, lo.x, lo.y};
+            split4(a1, hi, lo);
+            dst[RW] = u32x4{hi.x, hi.y, lo.x, lo.y};
         }
     };
 
@@ -290,8 +338,11 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     for (int k = 0; k < CB; ++k) {
         const int buf = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's share of chunk k has landed
+        MF_STAMP(0);
         __syncthreads();                         // ... everybody's has; everybody is done with the other buffers
+        MF_STAMP(1);
         issue(k + 1 < CB ? k + 1 : 0, buf ^ 1, k + 1 == CB);      // after the last chunk: chunk 0 again, for pass 2
+        MF_STAMP(2);
 #pragma unroll
         for (int it = 0; it < L_NI; ++it) {
             const int code = lrc_[it];
@@ -302,8 +353,11 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
                 Ls[gg * LPL + r * LWD + c] = v;
             }
         }
+        MF_STAMP(3);
         conv_kv(1, buf);
+        MF_STAMP(4);
         __syncthreads();
+        MF_STAMP(5);
         if (HBUF == 1) issue_hr(k + 1 < CB ? k + 1 : 0, 0);      // single hr buffer: free now that the key records are built
         // query conv, lane local: channels 4g..4g+3 of this lane's own pixel
         const f32x4 *w = Wd + (buf * 3 + 0) * 10 * G;
@@ -315,6 +369,8 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         u32x2 qh, ql;
         split4(qv, qh, ql);
         const u32x6 q6 = pack6(qh, ql);
+        MF_STAMP(6);
+        if (k + 1 == CB) load_head(0);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const h16x8 a = __builtin_bit_cast(h16x8, ka[b * RW]);
@@ -322,6 +378,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
             S[b] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, op_b(q6), S[b], 0, 0, 0);
         }
         if (k + 1 == CB) commit_head(buf ^ 1);
+        MF_STAMP(7);
     }
 
     // ------------------------------------------------------------------ softmax over the 49 taps (padding taps included)
@@ -361,6 +418,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         inv = 1.0f / z;                            // applied to the weighted sum instead of the 128 weights
     }
 
+    MF_STAMP(8);
     f32x4 lg[NBA];
 #pragma unroll
     for (int nb = 0; nb < NBA; ++nb) lg[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -374,12 +432,17 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     for (int k = 0; k < CB; ++k) {
         const int buf = (k + CB) & 1;            // continues the alternation of pass 1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MF_STAMP(9);
         __syncthreads();
+        MF_STAMP(10);
         if (k + 1 < CB) issue(k + 1, buf ^ 1, true);
         conv_kv(2, buf);
         const f32x4 lrc = lr_up(Lw + buf * LWCAP, yq + 1, xq + 1, g);      // residual term, channels 4g..4g+3 (table rows clamp into the image)
+        MF_STAMP(11);
         __syncthreads();
+        MF_STAMP(12);
         if (HBUF == 1 && k + 1 < CB) issue_hr(k + 1, 0);
+        if (k + 1 < CB) load_head(k + 1);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -402,6 +465,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
             }
         }
         if (k + 1 < CB) commit_head(buf ^ 1);
+        MF_STAMP(13);
     }
 
     // ------------------------------------------------------------------ logits: lg[nb][i] = class 16nb + 4g + i of query q
@@ -436,6 +500,12 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
                 store4_buf(__float_as_uint(lg[nb][i]), l_rsrc, (inq && cls < p.n_cls) ? off : OOB);
             }
     }
+    MF_STAMP(14);
+#ifdef MFMA_TIMING
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 15; ++i) atomicAdd(&g_mfma_dbg[16 * (threadIdx.x >> 6) + i], tacc_[i]);
+    if (threadIdx.x == 0) atomicAdd(&g_mfma_dbg[15], 1ull);
+#endif
 }
 
 template <int NB, int TY>
@@ -452,6 +522,14 @@ int launch(const CreffParams &p, hipStream_t st) {
 }
 
 }  // namespace
+
+#ifdef MFMA_TIMING
+extern "C" void arseg__mfma_dbg_read(unsigned long long *host, int reset) {
+    (void)hipDeviceSynchronize();
+    if (host) (void)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_mfma_dbg), sizeof(unsigned long long) * 256);
+    if (reset) { static unsigned long long z[256]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mfma_dbg), z, sizeof(z)); }
+}
+#endif
 
 int arseg_creff_mfma_launch(const CreffParams &p, hipStream_t st) {
     if (p.C & 15) return ARSEG_EUNSUPPORTED;

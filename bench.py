@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--variant-steps", type=int, default=9)
     ap.add_argument("--conv-layers", metavar="FILE", help="also write the per-layer conv table (shape, plan, us, TFLOP/s, fraction of the MFMA peak) as JSON")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
+    ap.add_argument("--gops-per-rank", type=int, default=1, help="GOPs per rank per step (experiment: a larger LR batch per launch sequence; 1 = one GOP-12 clip per GPU as BASELINE configs[1] says)")
     ap.add_argument("--plan", choices=["both", "exchange", "local"], default="both",
                     help="N > 1: `value` is always the mandated exchange plan; both / local also time SURVEY 8e's zero-communication comparison plan "
                          "(whole GOP per rank) and print it as plans.local")
@@ -200,7 +201,8 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         out, p_c8 = ev.alter_res_step_fast(lr, ref_p.unsqueeze(0), img, mvq, SCALE)
         return out
 
-    runner = GopRunner(key_fn, nonkey_fn, n_gops=world, gop=GOP)
+    GPR = max(1, int(args.gops_per_rank))          # GOPs per rank per step (1 = BASELINE's clip per GPU; > 1: an experiment knob, the batch of a step grows)
+    runner = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP)
     clips = {}
     needed = set(runner.my_gops) | {g for g, _ in runner.plan}
     for g in sorted(needed):
@@ -234,10 +236,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     # exchange.  Same kernels, same work per rank; timed after the mandated plan with the same K, reported beside it as plans.local
     step_local = None
     if world > 1 and full and args.plan in ("both", "local"):
-        runner_l = GopRunner(key_fn, nonkey_fn, n_gops=world, gop=GOP, local=True)
-        g_own = runner_l.my_gops[0]
-        fl = torch.cat([torch.from_numpy(clips[g_own]["frames"][d:d + 1]) for _, d in runner_l.plan]).to(dev)
-        ml = torch.cat([torch.from_numpy(clips[g_own]["mv"][d:d + 1]) for _, d in runner_l.plan]).to(dev)
+        runner_l = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP, local=True)
+        fl = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner_l.plan]).to(dev)
+        ml = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in runner_l.plan]).to(dev)
         step_local = make_step(runner_l, fl, ml)
 
     # Consecutive GOPs are independent: rotating them over a few HIP streams lets the MFMA-bound backbone convs of one GOP
@@ -291,7 +292,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     _log("timed region")
     steps_requested = steps
     elapsed, outs = timed_region(steps)
-    requested_run = {"steps": steps, "timed_s": elapsed, "value": world * (GOP - 1) * steps / elapsed}      # the run the command line asked for, as timed
+    requested_run = {"steps": steps, "timed_s": elapsed, "value": world * GPR * (GOP - 1) * steps / elapsed}      # the run the command line asked for, as timed
     steps_note = None
     min_s = MIN_TIMED_S if full else 0.3 * MIN_TIMED_S          # variant lines: a shorter window, still far above launch jitter
     if elapsed < min_s:
@@ -306,9 +307,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     if step_local is not None:
         run_steps(max(2, warmup // 2), step_local)
         l_el, _ = timed_region(steps, step_local)
-        plans = {"exchange": {"value": world * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+        plans = {"exchange": {"value": world * GPR * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
                               "what": "the mandated plan: frames dealt round-robin, one all-gather of the keyframe features per step on a side stream under phase 1"},
-                 "local": {"value": world * (GOP - 1) * steps / l_el, "ms_per_step": 1e3 * l_el / steps,
+                 "local": {"value": world * GPR * (GOP - 1) * steps / l_el, "ms_per_step": 1e3 * l_el / steps,
                            "what": "SURVEY 8e comparison line: whole GOP per rank, no exchange (same kernels, same work per rank)"},
                  "exchange_cost_frac": 1.0 - l_el / elapsed, "unit": "frames/s", "steps": steps}
     exchange_stats = None
@@ -334,10 +335,10 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         e_steps = max(len(streams), int(math.ceil(0.5 / max(elapsed / steps, 1e-6))))
         e_el, _ = timed_region(e_steps)
         gop_graph = g_keep
-        eager = {"value": world * (GOP - 1) * e_steps / e_el, "unit": "frames/s", "ms_per_step": 1e3 * e_el / e_steps, "steps": e_steps,
+        eager = {"value": world * GPR * (GOP - 1) * e_steps / e_el, "unit": "frames/s", "ms_per_step": 1e3 * e_el / e_steps, "steps": e_steps,
                  "note": "the same step enqueued eagerly from Python (no HIP graph), as every rank does at N > 1"}
 
-    nonkey_per_step = world * (GOP - 1)
+    nonkey_per_step = world * GPR * (GOP - 1)
     result = {
         "metric": {"psp": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
                    "psp2k": "non-keyframe frames/sec (backbone+CReFF), PSPNet-18 1024x2048 / LR 512x1024",
@@ -358,7 +359,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
-        "all_frames_per_s": world * GOP * steps / elapsed,
+        "all_frames_per_s": world * GPR * GOP * steps / elapsed,
     }
     if eager is not None:
         result["eager_launches"] = eager

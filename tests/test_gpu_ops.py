@@ -1201,6 +1201,13 @@ def test_creff_warp_fused(dev, Hp, Wp, hp, wp, n_cls, logsm, layout, impl, seg_r
         lay = _lib.C8 if layout == "c8" else _lib.NHWC
         prev = ops.configure(creff_warp_impl=impl, creff_seg_rows=seg_rows, creff_max_wgs=max_wgs)
         try:
+            if impl == "roll" and n_cls > 16:
+                # one dispatch rule (tests/test_host_config.py::test_creff_dispatch_table): the rolling kernel has no 17-32-class head; pinned to it
+                # such a launch is refused, under AUTO it runs on the tile kernel
+                with pytest.raises(_lib.ArsegError):
+                    ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, head, logsm, 7, 7, p_layout=lay)
+                ops.configure(creff_warp_impl="")
+                assert ops.creff_warp_kernel(N, C, Hp, Wp, hp, wp, n_cls) == "tiles"
             p, logits = ops.creff_warp(refs_d, mvq.to(dev), ops.to_nhwc(lr.to(dev)), pa, head, logsm, 7, 7, p_layout=lay)
         finally:
             ops.configure(**prev)
