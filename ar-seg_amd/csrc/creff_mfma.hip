@@ -248,23 +248,29 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         // the source addresses are recomputed per chunk from an opaque copy of the thread id: as loop invariants hipcc keeps three 64-bit
         // per-lane pointers live across both chunk loops, spills them and reloads them from scratch in every iteration (a vmcnt wait
         // that also waits for the LDS-DMA just issued)
-        int tid = tid_; asm volatile("" : "+v"(tid));
-        if (wave_u * 64 < lw_tot) {
+        // (r5) the lr window is requested by the upper half of a 16-wave workgroup and the weights by waves 6 / 7: with everything on the lowest waves,
+        // wave 0 issued twice the requests of the mean wave and every barrier waited for it (tools/time_mfma.py)
+        constexpr int LW0 = NT == 1024 ? 512 : 0, WD0 = NT == 1024 ? 384 : 0;
+        int tid = tid_ - LW0; asm volatile("" : "+v"(tid));
+        const int wave_l = wave_u - LW0 / 64;
+        if (wave_l >= 0 && wave_l * 64 < lw_tot) {
             const int i = min(tid, lw_tot - 1);          // surplus lanes of the last wave repeat the last item (stay inside Lw)
             // divisions by the (uniform) window extents as multiply-high with SGPR constants: hipcc's own expansion hoists its VGPR reciprocals
             // out of the chunk loops, where they were spilled and reloaded behind the DMA requests (r5)
             const int npx = ly_n * lx_n, gg = (int)__umulhi((unsigned)i, m_npx), px = i - gg * npx, r = (int)__umulhi((unsigned)px, m_lxn), c = px - r * lx_n;
             const float *src = p.lr + ((size_t)n * p.hp * p.wp + (size_t)(ly_lo + r) * p.wp + lx_lo + c) * p.C + k * 16 + gg * 4;
-            if (tid < lw_tot) dma16_glb(src, lds_addr(Lw + buf * LWCAP + wave_u * 64));
+            if (tid < lw_tot) dma16_glb(src, lds_addr(Lw + buf * LWCAP + wave_l * 64));
         }
-        if (wave_u * 64 < 3 * 10 * G) {                  // depthwise weights [9][C] + biases of the chunk
+        tid += LW0 - WD0;
+        const int wave_w = wave_u - WD0 / 64;
+        if (wave_w >= 0 && wave_w * 64 < 3 * 10 * G) {                  // depthwise weights [9][C] + biases of the chunk
             const int t = min(tid, 3 * 10 * G - 1);
             const int gg = t & 3, tp = (t >> 2) % 10, cv = t / (G * 10);
             const float *w = cv == 0 ? p.wq : (cv == 1 ? p.wk : p.wv);
             const float *bb = cv == 0 ? p.bq : (cv == 1 ? p.bk : p.bv);
             const int c = k * 16 + gg * 4;
             const float *src = tp < 9 ? w + (size_t)tp * p.C + c : bb + c;
-            if (tid < 3 * 10 * G) dma16_glb(src, lds_addr(Wd + buf * 3 * 10 * G + wave_u * 64));
+            if (tid < 3 * 10 * G) dma16_glb(src, lds_addr(Wd + buf * 3 * 10 * G + wave_w * 64));
         }
         (void)head;
     };
