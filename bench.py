@@ -303,6 +303,26 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         steps_note = (f"--steps {steps_requested} lasted {requested_run['timed_s']:.3f} s ({requested_run['value']:.0f} frames/s, `requested_run`): shorter than the "
                       f"{min_s:.1f} s this bench trusts, so `value` / `steps` / `ms_per_step` are from a second region of {steps} = {steps // steps_requested} x "
                       f"{steps_requested} steps, timed the same way (barrier + synchronize on both sides, max over ranks)")
+    # N > 1: the rolling CReFF kernel's persistent workgroups hold EVERY compute unit for ~1.7 ms at a time, and an RCCL kernel that cannot get a
+    # compute unit on one GPU keeps its peers' RCCL kernels spinning on theirs.  Whether leaving a few compute units to the collective pays cannot
+    # be measured on the 1-GPU boxes this was built on, so the first multi-GPU run decides it by measurement: the same K steps once more with
+    # `creff_max_wgs` = CUs - 16, and the faster of the two IS the configuration (both are printed; the decision uses the max-over-ranks times,
+    # so every rank takes the same one)
+    reserve = None
+    if world > 1 and full and not fused_tail and ops.config.creff_max_wgs == 0:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        all_cus = {"creff_max_wgs": 0, "value": world * GPR * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps}
+        ops.configure(creff_max_wgs=max(1, cus - 16))
+        run_steps(max(2, len(streams)))
+        r_el, r_outs = timed_region(steps)
+        res_cus = {"creff_max_wgs": max(1, cus - 16), "value": world * GPR * (GOP - 1) * steps / r_el, "ms_per_step": 1e3 * r_el / steps}
+        if r_el < elapsed:
+            elapsed, outs = r_el, r_outs
+        else:
+            ops.configure(creff_max_wgs=0)
+        reserve = {"all_compute_units": all_cus, "sixteen_left_to_the_collective": res_cus, "chosen_creff_max_wgs": ops.config.creff_max_wgs,
+                   "what": "the mandated exchange plan timed twice with the same K: the CReFF kernel on every compute unit / 16 compute units left free for the RCCL "
+                           "kernels; `value` is the faster one"}
     plans = None
     if step_local is not None:
         run_steps(max(2, warmup // 2), step_local)
@@ -367,6 +387,8 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         result["plans"] = plans
     if exchange_stats is not None:
         result["exchange"] = exchange_stats
+    if reserve is not None:
+        result["creff_compute_units"] = reserve
     # operand range of the split-fp16 convs: the sticky device word, read once after the timed region (ops.range_tripped)
     result["range_guard"] = {"mode": ops.config.conv_range_guard, "tripped": bool(ops.range_tripped())}
 
