@@ -177,39 +177,6 @@ def conv3x3_rows(x: PaddedRows, pc, residual=None, out_padded: bool = False, out
     return PaddedRows(o, x.pad) if out_padded else o
 
 
-def wino2_eligible(pc, cin: int) -> bool:
-    """The shapes arseg_conv3x3_wino2_fwd takes: 3x3, stride 1, pad 1, dilation 1, 64 -> 64 channels, fp32-grade (f16x3) arithmetic."""
-    return (sw.IGEMM3 and gemm_x3_enabled() and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1 and pc.dil == 1 and cin == 64 and pc.cin == 64
-            and pc.cout == 64)
-
-
-def conv3x3_wino2(x: torch.Tensor, pc, residual=None, out: Optional[torch.Tensor] = None, up2: bool = False, record: bool = True):
-    """3x3 conv 64 -> 64 as the fused Winograd F(2x2,3x3) kernel (arseg_conv3x3_wino2_fwd, csrc/wino2.hip): transforms and GEMMs of an 8 x 8 block on chip.
-    up2: the conv runs on the x2 bilinear upsample of ``x`` (PSPUpsample), blended while the input patch is built."""
-    _need_gpu(x, residual, out)
-    n, h, w, cin = x.shape
-    H, W = (2 * h, 2 * w) if up2 else (h, w)
-    if not wino2_eligible(pc, cin):
-        raise _lib.ArsegError("conv3x3_wino2: a 3x3 stride-1 pad-1 conv 64 -> 64 under the f16x3 back end is required")
-    u, scale = pc.wino2()
-    if out is None:
-        out = torch.empty((n, H, W, 64), dtype=torch.float32, device=x.device)
-    elif tuple(out.shape) != (n, H, W, 64):
-        raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)}, expected {(n, H, W, 64)}")
-    if residual is not None and tuple(residual.shape) != (n, H, W, 64):
-        raise _lib.ArsegError("residual shape mismatch")
-    rw = _range_word(x.device) if sw.RANGE_MODE == "device" else None
-    flops = 2 * n * H * W * 64 * 9 * 64
-    args = (_ptr(x), _nhwc_ld(x), _ptr(u), _ptr(scale), _ptr(pc.bias), _ptr(residual), _nhwc_ld(residual) if residual is not None else 0, _ptr(out), _nhwc_ld(out),
-            n, H, W, 64, 64, pc.act, pc.slope, 1 if up2 else 0, _ptr(rw), 65504.0, _stream())
-    if record:
-        with tagged((n, H, W, 64, 64, 3, 1, 1, bool(up2), "wino2", flops)):
-            launch("conv2d", _lib.load().arseg_conv3x3_wino2_fwd, *args, flops=flops)
-    else:
-        check(_lib.load().arseg_conv3x3_wino2_fwd(*args), "conv3x3_wino2")
-    return out
-
-
 def gemm_rows16(x: torch.Tensor, pc, residual=None, out: Optional[torch.Tensor] = None, cfg: Optional[int] = None, record: bool = True):
     """1x1 stride-1 conv of the 16-bit storage path as a plain GEMM of the LDS-DMA kernel (arseg_gemm_rows16_fwd): x NHWC fp16 / bf16 with dense
     rows (Cin % 64 == 0), 16-bit output (may be a channel slice).  cfg None: the tile shape is timed on first use per (M, K, N)."""

@@ -93,25 +93,6 @@ class PackedConv:
             cache[dtype] = (torch.from_numpy(packed.view(np.int16)).to(self.w.device).view(dtype), cin_pad)
         return cache[dtype]
 
-    def wino2(self):
-        """(u_split, scale) for arseg_conv3x3_wino2_fwd -- the fused Winograd F(2x2,3x3) kernel of the 64 -> 64 3x3 layers: U[16][Cout][Cin] = G g G^T, rows
-        scaled per output channel by a power of two (max |u| in [16, 32): the lo halves of the significant weights stay normal fp16 numbers) and split into
-        fp16 hi / lo; the inverse factor goes into the epilogue scale.  Built on first use."""
-        if "_wino2" not in self.__dict__:
-            lib = _lib.load()
-            if self.R != 3 or self.S != 3:
-                raise _lib.ArsegError("wino2(): 3x3 convs only")
-            u = np.empty((16, self.cout, self.cin), dtype=np.float32)
-            check(lib.arseg_wino2_pack_weight_host(_hp(self._w_oihw), self.cout, self.cin, _hp(u)), "wino2_pack_weight")
-            e = 5 - np.frexp(np.maximum(np.abs(u).max(axis=(0, 2)), 1e-30))[1]
-            us = np.ascontiguousarray(np.ldexp(u, e[None, :, None].astype(np.int32)), dtype=np.float32)
-            u_h3 = np.empty_like(us)
-            check(lib.arseg_split_weight_f16x3_host(_hp(us), 16 * self.cout, self.cin, _hp(u_h3), _hp(None)), "split_weight_f16x3")
-            base = np.ones(self.cout, dtype=np.float32) if self.scale is None else self.scale.detach().cpu().numpy()
-            dev = self.w.device
-            self._wino2 = (torch.from_numpy(u_h3).to(dev), torch.from_numpy((base * np.ldexp(np.float32(1.0), -e)).astype(np.float32)).to(dev))
-        return self._wino2
-
     def taps(self):
         """The nine taps of a 3x3 conv stacked along the output channels of ONE 1x1 conv (row t*Cout + co = W[co][.][t//3][t%3], no
         epilogue): the low-resolution GEMM of the tap-decomposed conv-after-upsample route (arseg_upconv3x3_tap_gather_fwd).  Built on

@@ -345,22 +345,6 @@ int arseg_upconv3x3_tap_gather_split_fwd(const float *z, int z_ld, const float *
                                          int Cout, int act, float prelu_slope, void *range_flag, float range_limit, arseg_stream_t stream);
 int arseg_wino43_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
 
-/* ---------------------------------------------------------------------------------------------
- * 3x3 stride-1 pad-1 convolution 64 -> 64 channels (+ scale / bias, residual, activation) as a FUSED Winograd F(2x2,3x3) (csrc/wino2.hip): input transform,
- * the sixteen 64 x 64 GEMMs (split-fp16 operands, three MFMAs per product: the fp32-grade arithmetic of ARSEG_MATH_F16X3) and the output transform of an
- * 8 x 8 pixel block stay on chip -- extractors.BasicBlock of layer1 (/root/reference/model/extractors.py:35-66) and PSPUpsample up_3
- * (/root/reference/model/pspnet.py:34-46).  2.25x fewer products than the direct conv, no transformed tensor in memory, no weight re-read (each of the 16
- * waves keeps its frequency's weight slice in registers).
- *   in       : NHWC fp32 [N][H][W][in_ld]; upsample2x != 0: [N][H/2][W/2][in_ld] and the conv runs on its x2 bilinear (align_corners=False) upsample (H, W even)
- *   u_split  : arseg_wino2_pack_weight_host (OIHW -> U[16][Cout][Cin] = G g G^T), rows scaled per output channel by a power of two and split with
- *              arseg_split_weight_f16x3_host([16 * Cout rows][Cin]); `scale` must carry the inverse factor (as for every ARSEG_MATH_F16X3 weight)
- *   out = act(scale[co] * conv + bias[co] + residual); residual / out NHWC fp32 with row strides res_ld / out_ld
- *   range_flag / range_limit: as arseg_conv_desc -- the kernel watches the TRANSFORMED activations it multiplies (up to 4x the input)
- * Cin == Cout == 64 only (ARSEG_EUNSUPPORTED otherwise); N H W in_ld 4 < 2 GiB. */
-int arseg_wino2_pack_weight_host(const float *w_oihw, int Cout, int Cin, float *out_host);
-int arseg_conv3x3_wino2_fwd(const float *in, int in_ld, const void *u_split, const float *scale, const float *bias, const float *residual,
-                            int res_ld, float *out, int out_ld, int N, int H, int W, int Cin, int Cout, int act, float prelu_slope,
-                            int upsample2x, void *range_flag, float range_limit, arseg_stream_t stream);
 
 /* Host-side weight preparation (the "weight packer"; CPU pointers).
  * arseg_packed_k: padded GEMM depth for a conv (multiple of 32).
