@@ -275,9 +275,10 @@ int arseg_psp_w2_split_fwd(const float *t, const float *unscale, void *out, int 
  * activations):   out[b][m][n] = act(scale[n] * sum_k x[b][m][k] * w[b][n][k] + bias[n] + residual[m][n])   (scale / bias / residual may
  * be NULL; residual fp32 [M][res_ld], batch == 1 only)
  * x_split [batch][M][K], w_split [batch][N][K] in split rows (batch strides in BYTES, multiples of 16), out fp32 [batch][M][out_ld]
- * (stride in floats), N % 4 == 0.  Operands reach LDS by LDS-DMA, no register staging (csrc/gemm_x3.hip).  tile_cfg 0..6
+ * (stride in floats), N % 4 == 0.  Operands reach LDS by LDS-DMA, no register staging (csrc/gemm_x3.hip).  tile_cfg 0..11
  * (M x N per workgroup): 0 = 256x256 with 8 waves, 1 = 256x256 with 16, 2 / 5 = 128x256 with 8 / 16, 3 = 128x128,
- * 4 = 256x128, 6 = 256x256 with 16 waves in two groups half a K step apart.  out_split != 0: `out` is written as split rows too (N % 32 == 0, out_ld == N) -- it is the next GEMM's x_split, e.g. the
+ * 4 = 256x128, 6 = 256x256 with 16 waves in two groups half a K step apart; 7 = 256x64, 8 = 128x64 with 4 waves, 9 = 128x64, 10 = 64x128, 11 = 128x128 with 32x64 wave
+ * tiles (round 5: narrow tiles for 64- / 128-channel outputs; anything else: ARSEG_EINVAL).  out_split != 0: `out` is written as split rows too (N % 32 == 0, out_ld == N) -- it is the next GEMM's x_split, e.g. the
  * PSP bottleneck feeding the tap-decomposed up_1 conv.  The same fp32-grade arithmetic as ARSEG_MATH_F16X3 (three fp16 MFMAs per product).
  * arseg_split_rows_fwd converts fp32 rows [rows][in_ld] (times `mul`, a power of two keeps it exact) to split rows [rows][K].
  * range_flag / range_limit (may be NULL / <= 0: 65504): the operand range word of arseg_conv_desc, set by whoever WRITES split rows from
