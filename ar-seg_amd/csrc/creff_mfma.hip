@@ -277,6 +277,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     // classifier slice [class][16 ch] of chunk k, entry = (group, class): requested right in front of a chunk's MFMA loop and committed behind it (r5: as
     // part of issue() the four registers were live through the whole iteration, across the convs that need every register they can get)
     auto load_head = [&](int k) {
+        int tid = tid_; asm volatile("" : "+v"(tid));          // (opaque: the class / group decode and the pointer are not worth a spilled register pair)
         if (NB > 0 && tid < G * NBA * 16) {
             const int cls = tid % (NBA * 16), gg = tid / (NBA * 16);
             pf_w = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -284,6 +285,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         }
     };
     auto commit_head = [&](int buf) {
+        int tid = tid_; asm volatile("" : "+v"(tid));
         if (NB > 0 && tid < G * NBA * 16) {
             u32x2 hi, lo;
             split4(pf_w, hi, lo);
@@ -332,7 +334,6 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     const u32x4 *ka = Kl + g * KPLK + (2 * pr) * RW + 8 * pc + q;             // A operand of the scores, row block 0
     // transpose read: lane i of a 16-lane group supplies the 8-byte piece (pixel 4g + i/4, channel group i%4) and receives
     // channel i of the group's 4 pixels (verified on gfx950: out[i][j] = halfword i%4 of the piece of lane 4j + i/4)
-    const unsigned char *va = reinterpret_cast<const unsigned char *>(Kl + (q & 3) * KPLV + (2 * pr) * RW + 8 * pc + 4 * g + (q >> 2));
 
     f32x4 S[8];
 #pragma unroll
@@ -431,7 +432,6 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
     const bool inq = gyq < p.Hp && gxq < p.Wp;
     const u32x4 p_rsrc = make_rsrc(p.p_out, p.p_bytes), l_rsrc = make_rsrc(p.logits, p.l_bytes);
     // p (C8 layout) offset of this lane's query in chunk k: ((((n C/8 + 2k + g/2) Hp + gyq) Wp + gxq) 8 + (g&1) 4) floats
-    const unsigned p_off0 = (((((unsigned)n * (unsigned)(p.C >> 3) + (unsigned)(g >> 1)) * p.Hp + gyq) * p.Wp + gxq) * 8u + (g & 1) * 4u) * 4u;
     const unsigned p_kstep = 2u * (unsigned)p.Hp * (unsigned)p.Wp * 32u;
 
     // ------------------------------------------------------------------ pass 2: weighted values, residual, head
@@ -443,13 +443,21 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
         MF_STAMP(10);
         if (k + 1 < CB) issue(k + 1, buf ^ 1, true);
         conv_kv(2, buf);
-        const f32x4 lrc = lr_up(Lw + buf * LWCAP, yq + 1, xq + 1, g);      // residual term, channels 4g..4g+3 (table rows clamp into the image)
+        int t2 = tid_; asm volatile("" : "+v"(t2));
+        const int q2 = t2 & 15, g2 = (t2 >> 4) & 3, w2 = t2 >> 6, pc2 = w2 & 1, pr2 = w2 >> 1;
+        const f32x4 lrc = lr_up(Lw + buf * LWCAP, 2 * pr2 + (q2 >> 3) + 1, 8 * pc2 + (q2 & 7) + 1, g2);      // residual term, channels 4g..4g+3 (table rows clamp into the image)
         MF_STAMP(11);
         __syncthreads();
         MF_STAMP(12);
         if (HBUF == 1 && k + 1 < CB) issue_hr(k + 1, 0);
         if (k + 1 < CB) load_head(k + 1);
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        // (r5) the transpose-read pointer and the store offset are rebuilt per chunk from an opaque thread id: as loop invariants they were hoisted,
+        // spilled, and their reloads sat behind the DMA requests of the next chunk
+        const unsigned char *va = reinterpret_cast<const unsigned char *>(Kl + (q2 & 3) * KPLV + (2 * pr2) * RW + 8 * pc2 + 4 * g2 + (q2 >> 2));
+        const int gy2 = ty0 + 2 * pr2 + (q2 >> 3), gx2 = tx0 + 8 * pc2 + (q2 & 7);
+        const unsigned p_off0 = (((((unsigned)n * (unsigned)(p.C >> 3) + (unsigned)(g2 >> 1)) * p.Hp + gy2) * p.Wp + gx2) * 8u + (g2 & 1) * 4u) * 4u;
+        const bool inq = gy2 < p.Hp && gx2 < p.Wp;
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const h16x8 a = pack8(lds_tr16(va + b * RW * 16), lds_tr16(va + b * RW * 16 + 8));
@@ -465,7 +473,7 @@ __global__ __launch_bounds__(64 * TY, 4) void creff_mfma_kernel(const CreffParam
             const u32x6 o6 = pack6(oh, ol);
 #pragma unroll
             for (int nb = 0; nb < NBA; ++nb) {
-                const h16x8 wa = __builtin_bit_cast(h16x8, Wfs[(buf * G + g) * NBA * 16 + nb * 16 + q]);
+                const h16x8 wa = __builtin_bit_cast(h16x8, Wfs[(buf * G + g2) * NBA * 16 + nb * 16 + q2]);
                 lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, op_a(o6), lg[nb], 0, 0, 0);
                 lg[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa, op_b(o6), lg[nb], 0, 0, 0);
             }
