@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_kernel(const ConvPa
 // upsampled 16-byte piece, a quarter of the bytes of the materialised tensor, and no resize kernel (its 0.25/0.75 arithmetic and
 // edge cases, layers.hip upsample2x_nhwc_kernel, are reproduced).  Dilation 1.
 template <int BN, int WM, bool UP2>      // WM wave rows of 64 output pixels each: BM = 64*WM pixels, 2*WM waves
-__global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv3x3_patch_kernel(const ConvParams p, int TW, int log2TW) {
+__global__ __launch_bounds__(128 * WM, (BN == 64 ? (WM == 2 ? 3 : 4) : 2)) void conv3x3_patch_kernel(const ConvParams p, int TW, int log2TW) {
     constexpr int ROWB = 144;                          // bytes per LDS row: 32 hi + 32 lo halves + pad (conflict-free b128 reads)
     constexpr int NT = 128 * WM, BM = 64 * WM;
     constexpr int TN = BN / 64, TM = 2, RB = (BN * 8 + NT - 1) / NT, RPB = NT / 8;
