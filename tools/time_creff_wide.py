@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""creff_mfma_kernel (C >= 128: BiSeNet 256 at 128x256, semseg 512) alone: us per launch and per frame for the bench shapes (11 frames, one frame)."""
 import sys, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from arseg_amd import _lib, ops, synth
 from arseg_amd.model import MyAttention
