@@ -59,14 +59,18 @@ class GopRunner:
     Returns {(gop index, d): output} for this rank's frames.
     """
 
-    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None, local: bool = False):
+    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None, local: bool = False, loopback: bool = False):
         self.key_fn, self.nonkey_fn = key_fn, nonkey_fn
         self.n_gops, self.gop, self.group = n_gops, gop, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
+        # loopback: a process group of ONE rank still issues the collective (side stream, gather buffer, the RCCL call itself) instead of
+        # short-cutting it -- the way to put the exchange code through RCCL on a 1-GPU box (tests, bench.py ARSEG_RCCL_LOOPBACK=1)
+        # (True / "all_gather": the batched plan's collective; "broadcast": the single-GOP plan's)
+        self.loopback = bool(loopback) and self.world == 1 and dist.is_available() and dist.is_initialized()
         self.local = bool(local) and self.world > 1
         self.timing = None           # enable_timing(): HIP events around the exchange and phase 1 of every run_overlapped step
-        self.single_gop = n_gops < self.world
+        self.single_gop = n_gops < self.world or (self.loopback and loopback == "broadcast" and n_gops == 1)
         if self.local and self.single_gop:
             raise ValueError("the local plan keeps whole GOPs per rank: it needs n_gops to be a multiple of the world size")
         if self.single_gop and n_gops != 1:
@@ -104,7 +108,7 @@ class GopRunner:
     def exchange(self, local_refs: Sequence[torch.Tensor], like: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
         """Keyframe features for every GOP, indexed by gop.  Batched plan: one all-gather; single-GOP plan: one broadcast from
         the owner (``like``: a tensor with the feature's shape / dtype / device for the ranks that own no keyframe)."""
-        if self.world == 1:
+        if self.world == 1 and not self.loopback:
             return list(local_refs)
         if self.local:                    # whole GOPs per rank: the features never leave the rank (indexed by gop like the other plans)
             return dict(zip(self.my_gops, local_refs))
@@ -146,7 +150,7 @@ class GopRunner:
         mvs)``.  Phase 1 (frame downscale + LR backbone) does not read ``ref_p``, so the collective's latency hides behind it.  On
         CPU tensors (gloo tests) the exchange simply runs first; the result is identical."""
         local_refs = [self.key_fn(keyframes[g]) for g in self.my_gops]
-        on_gpu = frames_stacked.is_cuda and self.world > 1 and not self.local
+        on_gpu = frames_stacked.is_cuda and (self.world > 1 or self.loopback) and not self.local
         if on_gpu:
             main = torch.cuda.current_stream()
             self._lane = main.cuda_stream

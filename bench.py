@@ -25,6 +25,10 @@ against the HBM roofline with the algorithmic bytes of SURVEY.md section 8d), `r
 MFMA peak, counted in the reference's direct-conv FLOPs), `cpu_baseline` (the oracle, i.e. a port, timed on the host cores for one
 non-keyframe of the same clip: 2 warm-up + 5 timed runs, median), `cpu_baseline_c1` (BASELINE configs[0]: PSPNet-18 HR 720x960 on the
 CPU) and `parity` (max-abs error and argmax agreement of that frame against the oracle).
+
+stdout carries the JSON line and nothing else (file descriptor 1 is pointed at stderr while the bench runs: RCCL prints a banner there).
+ARSEG_RCCL_LOOPBACK=1 (N = 1): the N > 1 step on a one-rank RCCL communicator, the collective really issued -- a check of the exchange path on a
+1-GPU box, marked `rccl_loopback` on the line.  ARSEG_DIST_BACKEND=gloo: rehearsal of an N-rank schedule on fewer GPUs than ranks.
 """
 import argparse
 import json
@@ -120,6 +124,13 @@ def main():
                     help="MFMA back end of the fp32 conv GEMMs: f16x3 = split-fp16 emulation (3 fp16 MFMAs, fp32 accumulate), f32 = fp32 MFMA")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner through C stdio when its first
+    # communicator is created, and the buffered text comes out at exit -- after the JSON line, seen with ARSEG_RCCL_LOOPBACK=1): from here on file
+    # descriptor 1 is stderr for everybody, and the result goes to the saved descriptor of the real stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -132,7 +143,15 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ARSEG_RCCL_LOOPBACK=1 (N = 1 only): a process group of ONE rank on RCCL, and the step of the N > 1 path -- eager launches, the all-gather of
+    # the keyframe feature on a side stream under phase 1, barriers and the max-over-ranks all-reduce around the timed region -- with the collective
+    # really issued (GopRunner(loopback=True)).  What a 1-GPU box can show of the multi-GPU path: RCCL initialises, the exchange code runs through it,
+    # the `exchange` diagnostics are produced.  The line is marked `rccl_loopback`; it is not a scaling measurement.
+    args.loopback = world == 1 and os.environ.get("ARSEG_RCCL_LOOPBACK", "0") not in ("", "0")
+    if args.loopback:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+    if world > 1 or args.loopback:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -141,7 +160,7 @@ def main():
 
     result = run_config(args, args.config, args.steps, args.warmup, world, rank, dev, backend, full=True)
     # ---- the other single-GPU BASELINE shapes, driver-timed in the same line (short runs)
-    if world == 1 and args.config == "psp" and not args.no_variants:
+    if world == 1 and args.config == "psp" and not args.no_variants and not args.loopback:
         result["variants"] = {}
         for name in ("psp_f32", "psp2k", "bise_bf16", "bise03_fp16"):
             try:
@@ -167,10 +186,16 @@ def main():
         result["value_strict_f32"] = result["variants"]["psp_f32"]["value"]
     if world > 1 and backend != "nccl":
         result["rehearsal"] = f"backend {backend}, {world} ranks on {torch.cuda.device_count()} GPU(s): schedule check, not a measurement"
-    if rank == 0:
-        print(json.dumps(result))
-    if world > 1:
+    if args.loopback:
+        result["rccl_loopback"] = ("one rank, backend nccl (RCCL): the N > 1 step (eager, all-gather of the keyframe feature on a side stream under phase 1) with the "
+                                   "collective issued on a one-rank communicator; checks the exchange path against RCCL on a 1-GPU box, not a scaling measurement")
+    if world > 1 or args.loopback:
+        dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    with os.fdopen(real_stdout, "w") as out:
+        if rank == 0:
+            out.write(json.dumps(result) + "\n")
 
 
 def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
@@ -202,7 +227,8 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         return out
 
     GPR = max(1, int(args.gops_per_rank))          # GOPs per rank per step (1 = BASELINE's clip per GPU; > 1: an experiment knob, the batch of a step grows)
-    runner = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP)
+    multi = world > 1 or getattr(args, "loopback", False)      # the step of the multi-rank path (at N = 1: the RCCL loopback check)
+    runner = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP, loopback=getattr(args, "loopback", False))
     clips = {}
     needed = set(runner.my_gops) | {g for g, _ in runner.plan}
     for g in sorted(needed):
@@ -224,7 +250,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     def make_step(rn, fb, mb):
         def step_():
             with torch.no_grad():
-                if world > 1 and not fused_tail:
+                if multi and not fused_tail:
                     # the exchange of the keyframe features runs on a side stream while the LR backbone (which does not read them) proceeds
                     return rn.run_overlapped(keyframes, fb, mb, lambda f: ev.alter_res_phase1(lr, f, SCALE),
                                              lambda feat, refs, mvq: ev.alter_res_phase2(lr, feat, refs, mvq))
@@ -249,7 +275,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     # per replay, static memory) and replayed; K steps = K // lanes replays + K % lanes eager steps.  N > 1 runs eagerly (the
     # exchange is an RCCL collective on a side stream).
     gop_graph = None
-    if world == 1 and not args.no_graph:
+    if not multi and not args.no_graph:
         from arseg_amd.executor import GopGraph
         with torch.cuda.stream(streams[0]):
             gop_graph = GopGraph([step] * len(streams), warmup=1, independent=not args.joined_graph)
@@ -271,17 +297,17 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
 
     def timed_region(k, step=step):
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         o = run_steps(k, step)
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
-        if world > 1:
+        if multi:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt)
@@ -333,7 +359,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                            "what": "SURVEY 8e comparison line: whole GOP per rank, no exchange (same kernels, same work per rank)"},
                  "exchange_cost_frac": 1.0 - l_el / elapsed, "unit": "frames/s", "steps": steps}
     exchange_stats = None
-    if world > 1 and full and not fused_tail:
+    if multi and full and not fused_tail:
         # self-diagnosing exchange: a few more steps with HIP events around the side-stream collective and around phase 1
         runner.enable_timing()
         run_steps(2 * len(streams))

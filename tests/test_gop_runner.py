@@ -47,19 +47,30 @@ def _phase2(feat, refs, mvs):
 def _worker(rank, world, port, q, mode="batched"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_gops = 1 if mode == "single" else world
+    n_gops = 1 if mode in ("single", "loopback-broadcast") else world
     keys, frames, mvs = _data(n_gops)
-    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops, local=mode.startswith("local"))
+    loop = {"loopback": "all_gather", "loopback-overlapped": "all_gather", "loopback-broadcast": "broadcast"}.get(mode, False)
+    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops, local=mode.startswith("local"), loopback=loop)
+    if loop:
+        assert world == 1 and runner.loopback and runner.single_gop == (loop == "broadcast")
+        calls = []
+        for name in ("all_gather_into_tensor", "broadcast"):
+            def spy(*a, _f=getattr(dist, name), _n=name, **k):
+                calls.append(_n)
+                return _f(*a, **k)
+            setattr(dist, name, spy)
     like = torch.empty(3, 8, 8)
     if mode.startswith("local"):
         assert runner.plan == [(rank, d) for d in range(1, 12)]       # whole GOP `rank`, nothing from the other ranks' GOPs
-    if mode in ("overlapped", "local-overlapped"):        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
+    if mode in ("overlapped", "local-overlapped", "loopback-overlapped"):        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
         fs = torch.stack([frames[f] for f in runner.plan])
         ms = torch.stack([mvs[f] for f in runner.plan])
         res = runner.run_overlapped({g: keys[g] for g in runner.my_gops}, fs, ms, _phase1, _phase2)
         out = {f: res[i] for i, f in enumerate(runner.plan)}
     else:
         out = runner.run({g: keys[g] for g in runner.my_gops}, {f: frames[f] for f in runner.plan}, {f: mvs[f] for f in runner.plan}, like=like)
+    if loop:          # the one-rank group did issue its collective (it is not short-cut as without a process group)
+        assert calls == ["broadcast" if loop == "broadcast" else "all_gather_into_tensor"], calls
     hist = torch.tensor([float(len(out))])
     dist.all_reduce(hist)                                            # the confusion-matrix reduction pattern
     q.put((rank, {k: v.numpy().copy() for k, v in out.items()}, float(hist)))      # by value: a shared-memory tensor handle dies with the worker
@@ -71,12 +82,14 @@ import pytest
 
 
 @pytest.mark.parametrize("world,mode", [(2, "batched"), (2, "overlapped"), (2, "single"), (4, "batched"), (4, "single"),
-                                        (8, "overlapped"), (8, "single"), (2, "local"), (4, "local-overlapped")])
+                                        (8, "overlapped"), (8, "single"), (2, "local"), (4, "local-overlapped"),
+                                        (1, "loopback"), (1, "loopback-overlapped"), (1, "loopback-broadcast")])
 def test_multi_rank_gloo_matches_single_process(world, mode):
     """world 2 / 4 / 8 over gloo == the single-process run, bit for bit: the batched plan (all-gather), the overlapped schedule (exchange
     concurrent with phase 1) and the single-GOP plan (owner broadcasts ref_p, 11 frames dealt over the ranks -- at world 8 three ranks
     get two frames and five get one: the literal north-star configuration, BASELINE configs[3] is the batched plan at world 8); and the
-    zero-communication comparison plan of SURVEY 8e ("local": rank g keeps GOP g whole, no collective on the data path)."""
+    zero-communication comparison plan of SURVEY 8e ("local": rank g keeps GOP g whole, no collective on the data path).  world 1
+    "loopback": a one-rank group that still issues its collective (how the exchange code meets RCCL on a 1-GPU box)."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -90,7 +103,7 @@ def test_multi_rank_gloo_matches_single_process(world, mode):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n_gops = 1 if mode == "single" else world
+    n_gops = 1 if mode in ("single", "loopback-broadcast") else world
     keys, frames, mvs = _data(n_gops)
     single = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops).run(keys, frames, mvs)     # no process group -> world 1
     merged = {}

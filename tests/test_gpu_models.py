@@ -521,14 +521,19 @@ def _nccl_worker(rank, world, port, q, mode):
     torch.cuda.set_device(rank)
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    ops.configure(conv_autotune=False)          # the same launch plans in every process: the comparison is bit for bit
     H, W = 64, 96
     hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
     lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
     synth.load_synth_weights(hr, 0)
     synth.load_synth_weights(lr, 1)
     hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
-    n_gops = 1 if mode == "single" else world
-    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12)
+    n_gops = 1 if mode in ("single", "loopback-broadcast") else world
+    loop = {"loopback": "all_gather", "loopback-broadcast": "broadcast"}.get(mode, False)      # one rank, the collective still issued
+    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12, loopback=loop)
+    assert bool(runner.loopback) == bool(loop)
+    if loop:
+        runner.enable_timing()
     clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
     keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
     fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner.plan]).to(dev)
@@ -540,26 +545,31 @@ def _nccl_worker(rank, world, port, q, mode):
         hist = torch.tensor([float(out.shape[0])], device=dev)
         dist.all_reduce(hist)                                        # the confusion-matrix reduction (evaluation.py:134-135) on RCCL
     torch.cuda.synchronize()
+    if loop:          # the side-stream collective ran (HIP events around it were recorded and can be read)
+        st = runner.exchange_stats()
+        assert st is not None and st["steps"] == 1 and st["exchange_ms"] > 0 and st["plan"] == ("broadcast" if loop == "broadcast" else "all_gather"), st
     q.put((rank, list(runner.plan), out.cpu().numpy().copy(), float(hist)))      # by value: a shared-memory handle dies with the worker
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["batched", "single"])
+@pytest.mark.parametrize("mode", ["batched", "single", "loopback", "loopback-broadcast"])
 def test_two_rank_rccl_matches_single_process(dev, mode):
     """The N-rank HIP path over RCCL (backend "nccl") equals the 1-rank path bit for bit: 2 ranks, the all-gather plan with the
-    exchange overlapped with phase 1, and the single-GOP broadcast plan.  Needs two GPUs (skipped on a 1-GPU box)."""
+    exchange overlapped with phase 1, and the single-GOP broadcast plan.  Needs two GPUs (skipped on a 1-GPU box).
+    loopback / loopback-broadcast: ONE rank whose process group still issues the all-gather / broadcast on the side stream
+    (GopRunner(loopback=...)) -- RCCL initialised on this box and the exchange code run through it; runs on a 1-GPU box."""
     import socket
 
     import torch.multiprocessing as mp
 
-    if torch.cuda.device_count() < 2:
+    world = 1 if mode.startswith("loopback") else 2
+    if torch.cuda.device_count() < world:
         pytest.skip("needs >= 2 GPUs")
     from arseg_amd import evaluation as ev
     from arseg_amd import ops, synth
     from arseg_amd.model import PSPNet, PSPNetWithFuse
 
-    world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -573,25 +583,30 @@ def test_two_rank_rccl_matches_single_process(dev, mode):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    # single-process reference on this process' GPU
-    H, W = 64, 96
-    hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
-    lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
-    synth.load_synth_weights(hr, 0)
-    synth.load_synth_weights(lr, 1)
-    hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
-    n_gops = 1 if mode == "single" else world
-    total = 0
-    for rank, plan, out, hist in results:
-        assert hist == n_gops * 11
-        total += len(plan)
-        for i, (g, d) in enumerate(plan):
-            clip = synth.make_clip(g, H, W, gop=12)
-            with torch.no_grad():
-                ref = ops.to_nhwc(hr(torch.from_numpy(clip["frames"][0:1]).to(dev))[-1])
-                want, _ = ev.alter_res_step_fast(lr, ref, torch.from_numpy(clip["frames"][d:d + 1]).to(dev), torch.from_numpy(clip["mv"][d:d + 1]).to(dev), 0.5)
-            assert np.array_equal(out[i:i + 1], want.cpu().numpy()), (rank, g, d)
-    assert total == n_gops * 11
+    # single-process reference on this process' GPU: the same batches with the same launch plans
+    prev = ops.configure(conv_autotune=False)
+    try:
+        H, W = 64, 96
+        hr = PSPNet(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18")
+        lr = PSPNetWithFuse(sizes=(1, 2, 3, 6), n_classes=12, psp_size=512, deep_features_size=256, backend="resnet18", atten_k=7)
+        synth.load_synth_weights(hr, 0)
+        synth.load_synth_weights(lr, 1)
+        hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
+        n_gops = 1 if mode in ("single", "loopback-broadcast") else world
+        clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
+        seen = set()
+        with torch.no_grad():
+            refs = {g: ops.to_nhwc(hr(torch.from_numpy(clips[g]["frames"][0:1]).to(dev))[-1])[0] for g in range(n_gops)}
+            for rank, plan, out, hist in results:
+                assert hist == n_gops * 11
+                fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in plan]).to(dev)
+                mb = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in plan]).to(dev)
+                want = ev.alter_res_phase2(lr, ev.alter_res_phase1(lr, fb, 0.5), [refs[g] for g, _ in plan], mb).cpu()
+                assert np.array_equal(out, want.numpy()), rank
+                seen.update(plan)
+        assert len(seen) == n_gops * 11
+    finally:
+        ops.configure(**prev)
 
 
 def _gloo_shared_gpu_worker(rank, world, port, q, mode):
