@@ -97,7 +97,7 @@ struct RollParams {
     const float *lr, *wq, *bq, *wk, *bk, *wv, *bv, *wf, *bf;
     float *p_out, *logits;
     int N, Hp, Wp, hp, wp, H, W, n_cls, log_softmax, p_layout, nstrips, nseg, seg_rows, balanced;
-    unsigned p_bytes, l_bytes, lr_bytes, ref_bytes;
+    unsigned p_bytes, l_bytes, lr_bytes, ref_bytes;      // of ONE frame: every frame has its own buffer descriptor
     float sy, sx;
     unsigned long long *dbg;
 };
@@ -302,8 +302,6 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
     f32x4 bias[NBA];                             // classifier bias of this lane's classes 16nb + 4g .. + 3 (-inf beyond n_cls: such a class
 #pragma unroll                                   // drops out of the log-softmax by itself)
     for (int nb = 0; nb < NBA; ++nb) bias[nb] = KH == 0 && NB > 0 ? *reinterpret_cast<const f32x4 *>(sm.Bfs + nb * 16 + 4 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out, 0, (int)p.p_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits, 0, (int)p.l_bytes, 0x00020000);
     RT_DECL;
     const int npieces = __builtin_amdgcn_readfirstlane(sc->count);
     for (int piece = 0; piece < npieces; ++piece) {
@@ -312,6 +310,9 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
         const int ys = __builtin_amdgcn_readfirstlane(pe.z), S = __builtin_amdgcn_readfirstlane(pe.w);
         const int x0 = strip * SW;
         RT_STEPS(S);
+        // one descriptor PER FRAME (scalar arithmetic per piece): the 32-bit buffer offsets then only have to span a frame, not the batch
+        const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.p_out + (size_t)n * (size_t)(CH * Hp) * Wp, 0, (int)p.p_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t l_rsrc = __builtin_amdgcn_make_buffer_rsrc(p.logits + (size_t)n * (size_t)(p.n_cls * Hp) * Wp, 0, (int)p.l_bytes, 0x00020000);
         // Store offsets of this lane's query pixel, split into a per-lane part that is constant down the strip (voffset; OOB for lanes
         // whose column or class lies outside) and a wave-uniform part that moves with the step (soffset: scalar arithmetic only).
         const int qy = q >> 3, gxq = x0 + 8 * pc + (q & 7);
@@ -320,7 +321,7 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
         const unsigned vp = !col_ok ? OOB : c8 ? ((unsigned)(g >> 1) * plane + (unsigned)(qy * Wp + gxq)) * 32u + (unsigned)(g & 1) * 16u
                                                : (unsigned)(qy * Wp + gxq) * (CH * 4u) + 16u * g;
         const unsigned p_cstep = c8 ? 2u * plane * 32u : 64u;                                    // chunk c: + c * p_cstep
-        const unsigned p_unit = c8 ? ((unsigned)n * 8u * plane + (unsigned)(ys * Wp)) * 32u : ((unsigned)n * plane + (unsigned)(ys * Wp)) * (CH * 4u);
+        const unsigned p_unit = (unsigned)(ys * Wp) * (c8 ? 32u : CH * 4u);
         const unsigned p_rstep = (unsigned)(2 * Wp) * (c8 ? 32u : CH * 4u);                     // step s: + s * p_rstep
         unsigned vl[NBA][4];
 #pragma unroll
@@ -330,7 +331,7 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                 const int cls = nb * 16 + 4 * g + i;
                 vl[nb][i] = col_ok && cls < p.n_cls ? ((unsigned)cls * plane + (unsigned)(qy * Wp + gxq)) * 4u : OOB;
             }
-        const unsigned l_unit = ((unsigned)n * (unsigned)p.n_cls * plane + (unsigned)(ys * Wp)) * 4u, l_rstep = (unsigned)(2 * Wp) * 4u;
+        const unsigned l_unit = (unsigned)(ys * Wp) * 4u, l_rstep = (unsigned)(2 * Wp) * 4u;
         f32x4 Oh[4];                                 // this half's un-normalised P.V (KH 0: carried to the merge in the next H1)
         float mh = 0.f, zh = 1.f;
 #pragma unroll
@@ -543,8 +544,8 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
         const int x0 = strip * SW;
         RT_STEPS(S);
         const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.ref[n]), 0, (int)p.ref_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr), 0, (int)p.lr_bytes, 0x00020000);
-        const unsigned lr_img = (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + 16u * gcg;
+        const __amdgpu_buffer_rsrc_t lr_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.lr) + (size_t)n * (size_t)(p.hp * p.wp) * CH, 0, (int)p.lr_bytes, 0x00020000);
+        const unsigned lr_img = 16u * gcg;           // (the frame is in the descriptor's base)
         const bool x_inner = x0 >= 3 && x0 + SW + 3 <= Wp;      // every record column of the strip inside the image
         // lr_up column taps of this lane's units: the same for every row of the strip
         bool l_lane[NLU > 0 ? NLU : 1];
@@ -782,7 +783,7 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                     arseg_src_index(p.sx, min(max(x0 - 1, 0), Wp - 1), true, p.wp, j0, j1, l);
                     arseg_src_index(p.sx, min(max(x0 + SW, 0), Wp - 1), true, p.wp, je0, je1, l);
                     const int r = i0 + (tq >> 4), c = j0 + (tq & 15);
-                    const unsigned off = r <= ie1 && c <= je1 ? (unsigned)n * (unsigned)(p.hp * p.wp) * (CH * 4u) + (unsigned)(r * p.wp + c) * (CH * 4u) : OOB;
+                    const unsigned off = r <= ie1 && c <= je1 ? (unsigned)(r * p.wp + c) * (CH * 4u) : OOB;
                     pft[0] = __builtin_amdgcn_raw_buffer_load_b32(lr_rsrc, off, 0, 0);
                     pft[1] = __builtin_amdgcn_raw_buffer_load_b32(lr_rsrc, off == OOB ? OOB : off + 128u, 0, 0);
                 }
@@ -915,8 +916,8 @@ int arseg_creff_roll_launch(const float *const *ref_nhwc_host, const int16_t *mv
         }
     }
     p.seg_rows = seg_rows; p.nseg = arseg_cdiv(Hp, seg_rows);
-    p.p_bytes = (unsigned)((size_t)N * CH * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)N * n_cls * Hp * Wp * sizeof(float)) : 0u;
-    p.lr_bytes = (unsigned)((size_t)N * CH * hp * wp * sizeof(float));
+    p.p_bytes = (unsigned)((size_t)CH * Hp * Wp * sizeof(float)); p.l_bytes = head ? (unsigned)((size_t)n_cls * Hp * Wp * sizeof(float)) : 0u;
+    p.lr_bytes = (unsigned)((size_t)CH * hp * wp * sizeof(float));
     p.ref_bytes = (unsigned)((size_t)CH * Hp * Wp * sizeof(float));
     p.sy = arseg_resize_scale(hp, Hp, true); p.sx = arseg_resize_scale(wp, Wp, true);
     p.dbg = nullptr;

@@ -780,8 +780,8 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
     ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
     if (C != CH || kH != 7 || kW != 7 || N > MAXN) return ARSEG_EUNSUPPORTED;
     if (p_layout != ARSEG_C8 && p_layout != ARSEG_NHWC) return ARSEG_EINVAL;
-    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)N * C * hp * wp * sizeof(float) >= (1ull << 31))
-        return ARSEG_EUNSUPPORTED;                                                             // 32-bit buffer offsets
+    if ((size_t)C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)C * hp * wp * sizeof(float) >= (1ull << 31))
+        return ARSEG_EUNSUPPORTED;                                                             // 32-bit buffer offsets within a frame
     if ((size_t)Hp * Wp >= (1u << 30)) return ARSEG_EUNSUPPORTED;                              // tap index packing
     if (!ARSEG_ALIGNED16(lr) || !ARSEG_ALIGNED16(p_out) || !ARSEG_ALIGNED16(wq) || !ARSEG_ALIGNED16(wk) || !ARSEG_ALIGNED16(wv) ||
         !ARSEG_ALIGNED16(bq) || !ARSEG_ALIGNED16(bk) || !ARSEG_ALIGNED16(bv))
@@ -804,6 +804,8 @@ extern "C" int arseg_creff_warp_fwd_ex(const float *const *ref_nhwc_host, const 
                                               log_softmax, N, Hp, Wp, hp, wp, seg_rows, max_wgs, false, arseg_stream(stream));
         if (e != ARSEG_EUNSUPPORTED || impl == ARSEG_CREFF_WARP_ROLL) return e;
     }
+    // the tile kernel addresses the whole batch through one descriptor per tensor (the rolling kernel: one per frame)
+    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)N * C * hp * wp * sizeof(float) >= (1ull << 31)) return ARSEG_EUNSUPPORTED;
     RRParams p;
     for (int i = 0; i < N; ++i) p.ref[i] = ref_nhwc_host[i];
     for (int i = N; i < MAXN; ++i) p.ref[i] = nullptr;
@@ -827,14 +829,16 @@ extern "C" int arseg_creff_warp_select(int N, int C, int Hp, int Wp, int hp, int
     if (N <= 0 || C <= 0 || Hp <= 0 || Wp <= 0 || hp <= 0 || wp <= 0 || n_cls < 0 || seg_rows < 0 || max_wgs < 0) return ARSEG_EINVAL;
     if (impl != ARSEG_CREFF_WARP_AUTO && impl != ARSEG_CREFF_WARP_TILES && impl != ARSEG_CREFF_WARP_ROLL) return ARSEG_EINVAL;
     if (C != CH || kH != 7 || kW != 7 || N > MAXN || n_cls > 32) return ARSEG_EUNSUPPORTED;
-    if ((size_t)N * C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)N * C * hp * wp * sizeof(float) >= (1ull << 31) || (size_t)Hp * Wp >= (1u << 30))
+    if ((size_t)C * Hp * Wp * sizeof(float) >= (1ull << 31) || (size_t)C * hp * wp * sizeof(float) >= (1ull << 31) || (size_t)Hp * Wp >= (1u << 30))
         return ARSEG_EUNSUPPORTED;
-    if (impl == ARSEG_CREFF_WARP_TILES) return ARSEG_CREFF_WARP_TILES;
+    // (the tile kernel: 32-bit offsets over the whole batch; the rolling kernel: over one frame)
+    const bool tiles_fit = (size_t)N * C * Hp * Wp * sizeof(float) < (1ull << 31) && (size_t)N * C * hp * wp * sizeof(float) < (1ull << 31);
+    if (impl == ARSEG_CREFF_WARP_TILES) return tiles_fit ? ARSEG_CREFF_WARP_TILES : ARSEG_EUNSUPPORTED;
     const int e = arseg_creff_roll_launch(nullptr, nullptr, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, ARSEG_NHWC, nullptr,
                                           nullptr, n_cls, nullptr, 0, N, Hp, Wp, hp, wp, seg_rows, max_wgs, true, nullptr);
     if (e == ARSEG_OK) return ARSEG_CREFF_WARP_ROLL;
     if (e != ARSEG_EUNSUPPORTED) return e;
-    return impl == ARSEG_CREFF_WARP_ROLL ? ARSEG_EUNSUPPORTED : ARSEG_CREFF_WARP_TILES;
+    return (impl == ARSEG_CREFF_WARP_ROLL || !tiles_fit) ? ARSEG_EUNSUPPORTED : ARSEG_CREFF_WARP_TILES;
 }
 
 extern "C" int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,

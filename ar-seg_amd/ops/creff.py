@@ -158,26 +158,38 @@ def creff_warp(refs_nhwc, mv_q: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=
             warp_mvq(refs[b].unsqueeze(0), mv_q[b:b + 1], _lib.C8, out=ref_c8[b:b + 1])
         p_c8, logits = creff(ref_c8, lr_nhwc, attn, head, log_softmax, kH, kW)
         return (p_c8 if p_layout == _lib.C8 else from_c8(p_c8, _lib.NHWC)), logits
-    per = max(1, min(32, ((1 << 31) - 1) // (C * Hp * Wp * 4)))          # frames per launch: 32-bit buffer offsets, 32 pointers
-    if B > per:
-        outs = [creff_warp(refs[i:i + per], mv_q[i:i + per], lr_nhwc[i:i + per], attn, head, log_softmax, kH, kW, p_layout)
-                for i in range(0, B, per)]
-        return torch.cat([o[0] for o in outs]), (None if outs[0][1] is None else torch.cat([o[1] for o in outs]))
+    n_cls = 0 if head is None else head[0].shape[0]
+    per = _warp_frames_per_launch(B, C, Hp, Wp, hp, wp, n_cls, kH, kW)
     shape = (B, C // 8, Hp, Wp, 8) if p_layout == _lib.C8 else (B, Hp, Wp, C)
     p_out = torch.empty(shape, dtype=torch.float32, device=lr_nhwc.device)
-    logits, wf, bf, n_cls = None, None, None, 0
+    logits, wf, bf = None, None, None
     if head is not None:
         wf, bf = head
-        n_cls = wf.shape[0]
         logits = torch.empty((B, n_cls, Hp, Wp), dtype=torch.float32, device=lr_nhwc.device)
-    ptrs = (ctypes.c_void_p * B)(*[r.data_ptr() for r in refs])
     impl = {"tiles": 1, "roll": 2}.get(config.creff_warp_impl, 0)
-    launch("creff_warp", _lib.load().arseg_creff_warp_fwd_ex, ptrs, _ptr(mv_q), H, W, _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq),
-            _ptr(attn.wk), _ptr(attn.bk), _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), p_layout, _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
-            1 if log_softmax else 0, B, C, Hp, Wp, hp, wp, kH, kW, impl, max(0, int(config.creff_seg_rows)), max(0, int(config.creff_max_wgs)), _stream(),
-            flops=B * Hp * Wp * C * (250 + 2 * n_cls),
-            nbytes=B * (4 * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp) + 4 * H * W))
+    for i in range(0, B, per):          # one launch unless the kernel's addressing caps it; every launch writes its slice of the one output
+        b = min(per, B - i)
+        ptrs = (ctypes.c_void_p * b)(*[r.data_ptr() for r in refs[i:i + b]])
+        launch("creff_warp", _lib.load().arseg_creff_warp_fwd_ex, ptrs, _ptr(mv_q[i:i + b]), H, W, _ptr(lr_nhwc[i:i + b]), _ptr(attn.wq), _ptr(attn.bq),
+                _ptr(attn.wk), _ptr(attn.bk), _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out[i:i + b]), p_layout, _ptr(wf), _ptr(bf), n_cls,
+                _ptr(None if logits is None else logits[i:i + b]), 1 if log_softmax else 0, b, C, Hp, Wp, hp, wp, kH, kW, impl,
+                max(0, int(config.creff_seg_rows)), max(0, int(config.creff_max_wgs)), _stream(),
+                flops=b * Hp * Wp * C * (250 + 2 * n_cls),
+                nbytes=b * (4 * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp) + 4 * H * W))
     return p_out, logits
+
+
+def _warp_frames_per_launch(B, C, Hp, Wp, hp, wp, n_cls, kH=7, kW=7) -> int:
+    """Frames one arseg_creff_warp_fwd_ex launch takes for this shape under the current knobs: 32 pointers; the rolling kernel addresses every
+    frame through its own buffer descriptor (any batch), the tile kernel the whole batch through one (N x C x Hp x Wp x 4 < 2 GiB) -- asked of
+    the library's own dispatch query, not restated here."""
+    impl = {"tiles": 1, "roll": 2}.get(config.creff_warp_impl, 0)
+    sel = _lib.load().arseg_creff_warp_select
+    args = (C, Hp, Wp, hp, wp, kH, kW, n_cls, impl, max(0, int(config.creff_seg_rows)), max(0, int(config.creff_max_wgs)))
+    per = min(B, 32)
+    if per > 1 and sel(per, *args) == _lib.ARSEG_EUNSUPPORTED:          # not as one launch: what the batch-wide descriptors admit
+        per = max(1, min(per, ((1 << 31) - 1) // (C * Hp * Wp * 4)))
+    return per
 
 
 def creff_warp_kernel(B: int, C: int, Hp: int, Wp: int, hp: int, wp: int, n_cls: int, kH: int = 7, kW: int = 7) -> str:
@@ -185,7 +197,7 @@ def creff_warp_kernel(B: int, C: int, Hp: int, Wp: int, hp: int, wp: int, n_cls:
     "two-kernel" (arseg_warp_mvq_fwd + arseg_creff_fwd: shapes the fused entry point does not cover).  A pure query of the library's own
     dispatch rule (arseg_creff_warp_select) -- bench.py labels its roofline line with it instead of restating the rule."""
     impl = {"tiles": 1, "roll": 2}.get(config.creff_warp_impl, 0)
-    per = max(1, min(32, ((1 << 31) - 1) // (C * Hp * Wp * 4)))
+    per = _warp_frames_per_launch(B, C, Hp, Wp, hp, wp, n_cls, kH, kW)
     st = _lib.load().arseg_creff_warp_select(min(B, per), C, Hp, Wp, hp, wp, kH, kW, n_cls, impl, max(0, int(config.creff_seg_rows)),
                                              max(0, int(config.creff_max_wgs)))
     if st == _lib.ARSEG_EUNSUPPORTED and impl != 2:

@@ -123,8 +123,10 @@ int arseg_creff_fwd(const float *hr, const float *lr, const float *wq, const flo
  *   mv_q : int16 quarter-pel [N,H,W,2] as in arseg_warp_mvq_fwd (resized to (Hp,Wp) in fp64 in-kernel)
  *   lr, wq..bv, wf, bf, logits, log_softmax : as arseg_creff_fwd
  *   p_out : the fused feature, layout p_layout = ARSEG_C8 [N,C/8,Hp,Wp,8] or ARSEG_NHWC [N,Hp,Wp,C]
- * Supported: C == 64, kH == kW == 7, N <= 32, n_cls <= 32, N*C*Hp*Wp*4 < 2 GiB; anything else
- * returns ARSEG_EUNSUPPORTED and the caller uses arseg_warp_mvq_fwd + arseg_creff_fwd.
+ * Supported: C == 64, kH == kW == 7, N <= 32, n_cls <= 32, C*Hp*Wp*4 < 2 GiB per frame (the rolling
+ * kernel addresses every frame through its own buffer descriptor; launches that fall to the tile kernel --
+ * 17-32 classes, impl = TILES -- need N*C*Hp*Wp*4 < 2 GiB); anything else returns ARSEG_EUNSUPPORTED and the
+ * caller uses arseg_warp_mvq_fwd + arseg_creff_fwd or splits the batch.
  * ------------------------------------------------------------------------------------------- */
 int arseg_creff_warp_fwd(const float *const *ref_nhwc_host, const int16_t *mv_q, int H, int W, const float *lr,
                          const float *wq, const float *bq, const float *wk, const float *bk, const float *wv,

@@ -1281,6 +1281,47 @@ def test_gop_graph_lanes(dev, independent):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["nhwc", "c8"])
+def test_creff_warp_batch_above_2gib_one_launch(dev, layout):
+    """A batch whose fused feature exceeds 2 GiB (11 frames of 768 x 1024 x 64 fp32 = 2.2 GB; PSPNet at 1024 x 2048 is the bench's case) runs as
+    ONE launch of the rolling kernel -- every frame has its own buffer descriptor, the 32-bit offsets span a frame -- and equals, bit for bit,
+    the same frames launched one at a time.  Pinned to the tile kernel (one descriptor per tensor) the batch is split instead: same values
+    within the two kernels' rounding."""
+    from arseg_amd import _lib, ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+
+    C, N, Hp, Wp, hp, wp, n_cls = 64, 11, 768, 1024, 384, 512, 12
+    assert N * C * Hp * Wp * 4 >= (1 << 31)
+    lay = _lib.C8 if layout == "c8" else _lib.NHWC
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    m = synth.load_synth_weights(MyAttention(C, kW=7, kH=7), 7, attn_gain=0.35)
+    pa = PackedAttention(m, dev)
+    refs = [torch.randn((Hp, Wp, C), generator=gen).to(dev) for _ in range(2)]
+    refs_d = [refs[i % 2] for i in range(N)]
+    lr = torch.randn((N, hp, wp, C), generator=gen).to(dev)
+    mvq = (torch.randint(-9, 10, (N, Hp, Wp, 2), generator=gen) * 4).to(torch.int16).to(dev)
+    head = (rnd(22, n_cls, C, scale=0.2).to(dev), rnd(23, n_cls, scale=0.1).to(dev))
+    assert ops.creff_warp_kernel(N, C, Hp, Wp, hp, wp, n_cls) == "roll"
+    with ops.profile() as prof:
+        p, logits = ops.creff_warp(refs_d, mvq, lr, pa, head, True, 7, 7, p_layout=lay)
+    assert prof.summary()["creff_warp"]["launches"] == 1
+    assert tuple(logits.shape) == (N, n_cls, Hp, Wp)
+    for i in (0, 5, 10):                        # first, middle, last frame: the offsets beyond 2 GiB are the last frames'
+        p1, l1 = ops.creff_warp(refs_d[i:i + 1], mvq[i:i + 1], lr[i:i + 1], pa, head, True, 7, 7, p_layout=lay)
+        assert torch.equal(p[i:i + 1], p1) and torch.equal(logits[i:i + 1], l1), i
+    prev = ops.configure(creff_warp_impl="tiles")
+    try:
+        with ops.profile() as prof:
+            pt, lt = ops.creff_warp(refs_d, mvq, lr, pa, head, True, 7, 7, p_layout=lay)
+        assert prof.summary()["creff_warp"]["launches"] == 2          # 10 frames fit below 2 GiB, then 1
+    finally:
+        ops.configure(**prev)
+    assert maxdiff(pt[-1:], p[-1:]) <= 2e-4 and maxdiff(lt[-1:], logits[-1:]) <= 4e-4
+    assert maxdiff(pt[:1], p[:1]) <= 2e-4
+
+
+@pytest.mark.gpu
 def test_creff_roll_schedules_vs_oracle_random(dev):
     """The rolling kernel on random small shapes (odd sizes, lr of any smaller size, 1-4 frames) under random schedules -- the balanced
     default and fixed segments, few and many workgroups -- against the oracle's warp -> MyAttention: every piece list must cover every
