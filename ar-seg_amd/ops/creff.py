@@ -92,11 +92,6 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
     _, hp, wp, C2 = lr_nhwc.shape
     if C2 != C:
         raise _lib.ArsegError(f"channel mismatch: hr has {C}, lr has {C2}")
-    if N > 1 and N * C * Hp * Wp * 4 >= (1 << 31):          # the kernel addresses p_out with 32-bit buffer offsets
-        h = N // 2
-        a = creff(hr_c8[:h], lr_nhwc[:h], attn, head, log_softmax, kH, kW)
-        b = creff(hr_c8[h:], lr_nhwc[h:], attn, head, log_softmax, kH, kW)
-        return torch.cat([a[0], b[0]]), (None if a[1] is None else torch.cat([a[1], b[1]]))
     p_out = torch.empty_like(hr_c8)
     logits, wf, bf, n_cls = None, None, None, 0
     if head is not None:
@@ -106,11 +101,14 @@ def creff(hr_c8: torch.Tensor, lr_nhwc: torch.Tensor, attn, head=None, log_softm
     # kernel choice: explicit arguments of the ABI; the knobs (A/B measurements, tests) live in ops.config, not in the library
     impl = {"mfma": 1, "valu": 2}.get(config.creff_impl, 0)
     tile_rows = config.creff_tile_rows
-    launch("creff", _lib.load().arseg_creff_fwd_ex, _ptr(hr_c8), _ptr(lr_nhwc), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
-                                      _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out), _ptr(wf), _ptr(bf), n_cls, _ptr(logits),
-                                      1 if log_softmax else 0, N, C, Hp, Wp, hp, wp, kH, kW, impl, tile_rows if tile_rows in (8, 16) else 0, _stream(),
-            flops=N * Hp * Wp * C * (250 + 2 * n_cls),
-            nbytes=4 * N * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp))
+    per = max(1, min(N, ((1 << 31) - 1) // (C * Hp * Wp * 4)))          # the kernels address p_out with 32-bit buffer offsets over the launch's batch
+    for i in range(0, N, per):          # (normally one launch; every launch writes its slice of the one output)
+        b = min(per, N - i)
+        launch("creff", _lib.load().arseg_creff_fwd_ex, _ptr(hr_c8[i:i + b]), _ptr(lr_nhwc[i:i + b]), _ptr(attn.wq), _ptr(attn.bq), _ptr(attn.wk), _ptr(attn.bk),
+               _ptr(attn.wv), _ptr(attn.bv), _ptr(p_out[i:i + b]), _ptr(wf), _ptr(bf), n_cls, _ptr(None if logits is None else logits[i:i + b]),
+               1 if log_softmax else 0, b, C, Hp, Wp, hp, wp, kH, kW, impl, tile_rows if tile_rows in (8, 16) else 0, _stream(),
+               flops=b * Hp * Wp * C * (250 + 2 * n_cls),
+               nbytes=4 * b * (2 * C * Hp * Wp + C * hp * wp + n_cls * Hp * Wp))
     return p_out, logits
 
 

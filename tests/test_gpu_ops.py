@@ -1322,6 +1322,29 @@ def test_creff_warp_batch_above_2gib_one_launch(dev, layout):
 
 
 @pytest.mark.gpu
+def test_creff_wide_batch_above_2gib_slices(dev):
+    """ops.creff (C >= 128 kernels: 32-bit offsets over a launch's batch) on a batch above 2 GiB: split into launches that write their slices of
+    ONE output (no concatenation pass), equal bit for bit to the frames launched alone."""
+    from arseg_amd import ops, synth
+    from arseg_amd.model import MyAttention
+    from arseg_amd.packing import PackedAttention
+
+    C, N, Hp, Wp, hp, wp, n_cls = 128, 5, 1024, 1024, 512, 512, 19
+    assert N * C * Hp * Wp * 4 >= (1 << 31)
+    gen = torch.Generator(device="cpu").manual_seed(6)
+    pa = PackedAttention(synth.load_synth_weights(MyAttention(C, kW=7, kH=7), 7, attn_gain=0.35), dev)
+    hr = torch.randn((N, C // 8, Hp, Wp, 8), generator=gen).to(dev)
+    lr = torch.randn((N, hp, wp, C), generator=gen).to(dev)
+    head = (rnd(22, n_cls, C, scale=0.2).to(dev), rnd(23, n_cls, scale=0.1).to(dev))
+    with ops.profile() as prof:
+        p, logits = ops.creff(hr, lr, pa, head, True, 7, 7)
+    assert prof.summary()["creff"]["launches"] == 2 and tuple(p.shape) == tuple(hr.shape) and tuple(logits.shape) == (N, n_cls, Hp, Wp)
+    for i in (0, 3, 4):
+        p1, l1 = ops.creff(hr[i:i + 1], lr[i:i + 1], pa, head, True, 7, 7)
+        assert torch.equal(p[i:i + 1], p1) and torch.equal(logits[i:i + 1], l1), i
+
+
+@pytest.mark.gpu
 def test_creff_roll_schedules_vs_oracle_random(dev):
     """The rolling kernel on random small shapes (odd sizes, lr of any smaller size, 1-4 frames) under random schedules -- the balanced
     default and fixed segments, few and many workgroups -- against the oracle's warp -> MyAttention: every piece list must cover every
