@@ -443,7 +443,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             # CReFF stage's launches -- every other lane keeps its kernels coming, so the stage shares the GPU exactly as it does in the
             # timed region (this, not the dense pass, is the duration rocprofv3 reports for the step)
             prof_instep = None
-            if not fused_tail:
+            # (N = 1 only: at N > 1 a step contains the exchange, and this block runs on rank 0 alone -- a collective nobody else enters never returns.
+            # Found by the 2-rank rehearsal, ARSEG_DIST_BACKEND=gloo; the N > 1 line has the exchange diagnostics instead)
+            if not fused_tail and not multi:
                 g_keep, gop_graph = gop_graph, None
                 run_steps(len(streams))
                 with ops.profile(only=("creff_warp", "creff", "warp_mvq")) as prof_instep:
