@@ -702,3 +702,43 @@ def test_two_ranks_on_one_gpu_gloo_match_single_process(dev, mode):
         assert len(seen) == n_gops * 11
     finally:
         ops.configure(**prev)
+
+
+@pytest.mark.parametrize("mode", ["rehearsal2", "rccl-loopback"])
+def test_bench_multi_rank_path_end_to_end(dev, mode):
+    """bench.py's N > 1 code path as the driver launches it, end to end, on the 1-GPU box: (rehearsal2) two ranks under torch.distributed.run that share
+    the GPU and exchange over gloo (ARSEG_DIST_BACKEND=gloo) -- every rank-0-only block of the bench must be free of collectives, or this hangs: it
+    did, in the in-step profile pass, until round 5 --; (rccl-loopback) one rank on RCCL with the collective issued (ARSEG_RCCL_LOOPBACK=1).  Both must end
+    with exactly ONE line on stdout, the JSON, carrying the exchange diagnostics (RCCL's banner used to land behind it)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    if mode == "rehearsal2":
+        env["ARSEG_DIST_BACKEND"] = "gloo"
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    else:
+        env.update(ARSEG_RCCL_LOOPBACK="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    ex = d["exchange"]
+    assert ex["plan"] == "all_gather" and ex["exchange_ms"] > 0 and len(ex["per_rank"]) == d["n_gpus"]
+    assert d["value"] > 0 and d["unit"] == "frames/s" and d["executor"] == "eager launches"
+    if mode == "rehearsal2":
+        assert d["n_gpus"] == 2 and "rehearsal" in d and d["plans"]["local"]["value"] > 0 and "creff_compute_units" in d
+    else:
+        assert d["n_gpus"] == 1 and "rccl_loopback" in d and ex["backend"] == "nccl"
