@@ -547,6 +547,9 @@ extern "C" void arseg__mfma_dbg_read(unsigned long long *host, int reset) {
 
 int arseg_creff_mfma_launch(const CreffParams &p, hipStream_t st) {
     if (p.C & 15) return ARSEG_EUNSUPPORTED;
+    //  the lr-window decode divides by multiply-high reciprocals floor(2^32 / d) + 1, which wrap to 0 for d == 1: an LR feature one
+    // pixel wide or high (a 1-wide window) runs on the VALU kernel instead (the dispatcher's fallback for EUNSUPPORTED)
+    if (p.hp < 2 || p.wp < 2) return ARSEG_EUNSUPPORTED;
     // the raw lr window under a tile (+1 halo, +1 for the second bilinear tap) must fit its LDS slot
     const int wy = (int)((16 + 1) * p.sy) + 3, wx = (int)((TX + 1) * p.sx) + 3;
     if (G * wy * wx > LWCAP) return ARSEG_EUNSUPPORTED;

@@ -45,6 +45,9 @@
 #ifndef ROLL_CPRIO
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
 #endif
+#ifndef ROLL_KSLOT5
+#define ROLL_KSLOT5 1         // key ring: window row r lives in ring slot (5 r) & 7 instead of r & 7 (see kslot below)
+#endif
 #include "warp_math.h"
 
 namespace {
@@ -90,6 +93,14 @@ constexpr int T_FIRST = -3;                         // first iteration of a segm
 constexpr int MAXN = 32;
 constexpr unsigned OOB = 0xFFFFFFF0u;
 constexpr float LOG2E = 1.44269504088896340736f;
+
+// Ring slot of key row r.  A consumer's ds_read_b128 of one key block takes 16 consecutive window keys e = 2b + q, which wrap from window
+// row b to row b + 1 at e = 14: with the rows in consecutive slots (pitch RW = 22 records) the lanes behind the wrap sit 22 - 14 = 8 records
+// = half a 256-byte bank row away from where a contiguous run would put them and collide with the lanes 8 records further on (2-way
+// conflicts on up to half of the lanes: profiles/r04_v1_pmc_creff_roll.json, SQ_LDS_BANK_CONFLICT = 26 % of the LDS-active cycles).  With
+// consecutive rows 5 slots apart (5 is coprime to 8: still a permutation of the ring) the wrap lands 5 * 22 - 14 = 96 = 0 mod 16 records
+// (or -3 * 22 - 14 = -80) further: the 16 lanes cover the 64 banks exactly once.
+__device__ __forceinline__ int kslot(int r) { return ROLL_KSLOT5 ? (5 * r) & 7 : r & 7; }
 
 struct RollParams {
     const float *ref[MAXN];       // un-warped keyframe feature of each frame, NHWC [Hp][Wp][64]
@@ -374,7 +385,7 @@ __device__ __forceinline__ void consumer(const RollParams &p, const Smem &sm, co
                 const int b8 = (2 * s) & 7;
                 int krec[NBK];
 #pragma unroll
-                for (int j = 0; j < NBK; ++j) krec[j] = ((kky[j] + b8) & 7) * RW + kkx[j];
+                for (int j = 0; j < NBK; ++j) krec[j] = kslot(kky[j] + b8) * RW + kkx[j];
                 f32x4 Sc[NBK];
 #pragma unroll
                 for (int j = 0; j < NBK; ++j) Sc[j] = maskv[j];
@@ -708,8 +719,8 @@ __device__ __forceinline__ void producer(const RollParams &p, const Smem &sm, co
                         f32x4 a, b;
                         stencil2r(wreg, row[0], row[1], row[2], row[3], a, b);
                         if (!(x_inner && r0 >= 0 && r0 + 1 < Hp)) { a = in_a ? a : zero; b = in_b ? b : zero; }      // (wave uniform)
-                        sm.Kr[kcg * KPL + ((2 * k) & 7) * RW + kx] = split4r(a);
-                        sm.Kr[kcg * KPL + (((2 * k) & 7) + 1) * RW + kx] = split4r(b);
+                        sm.Kr[kcg * KPL + kslot(2 * k) * RW + kx] = split4r(a);
+                        sm.Kr[kcg * KPL + kslot(2 * k + 1) * RW + kx] = split4r(b);
                     }
                 }
 #pragma unroll

@@ -171,7 +171,7 @@ def alter_res_step_fast(lr_net, ref_p_nhwc, img, mv_q, scale=0.5):
     lr_net = _unwrap(lr_net)
     N, C, H, W = img.shape
     h, w = _downscale_hw(H, W, scale)
-    feat = lr_net.phase1_nhwc4(ops.frame_ingest(img, h, w, lr_net.storage_dtype))[-1]     # a3 + phase 1
+    feat = lr_net.phase1_nhwc4(ops.frame_ingest(img, h, w, lr_net.storage_dtype), aux=ops.config.aux_outputs)[-1]     # a3 + phase 1
     return lr_net.phase2_warp(feat, [ref_p_nhwc[i] for i in range(N)], mv_q)      # a2 + a1 + CReFF + head
 
 
@@ -189,7 +189,7 @@ def alter_res_batch_fast(lr_net, ref_ps, imgs, mv_qs, scale=0.5):
         outs = [alter_res_batch_fast(lr_net, ref_ps[i:i + sub], imgs[i:i + sub], mv_qs[i:i + sub], scale) for i in range(0, B, sub)]
         return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
     h, w = _downscale_hw(H, W, scale)
-    feat = lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype))[-1]     # a3 + phase 1, batched
+    feat = lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype), aux=ops.config.aux_outputs)[-1]     # a3 + phase 1, batched
     return lr_net.phase2_warp(feat, list(ref_ps), mv_qs)               # a2 + a1 (each frame has its own MV map) + CReFF + head
 
 
@@ -199,7 +199,7 @@ def alter_res_phase1(lr_net, imgs, scale=0.5):
     lr_net = _unwrap(lr_net)
     B, _, H, W = imgs.shape
     h, w = _downscale_hw(H, W, scale)
-    return lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype))[-1]
+    return lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype), aux=ops.config.aux_outputs)[-1]
 
 
 def alter_res_phase2(lr_net, feat, ref_ps, mv_qs):
@@ -215,7 +215,7 @@ def alter_res_batch_pred(lr_net, ref_ps, imgs, mv_qs, scale=0.5, labels=None, hi
     lr_net = _unwrap(lr_net)
     B, _, H, W = imgs.shape
     h, w = _downscale_hw(H, W, scale)
-    feat = lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype))[-1]
+    feat = lr_net.phase1_nhwc4(ops.frame_ingest(imgs, h, w, lr_net.storage_dtype), aux=ops.config.aux_outputs)[-1]
     fused_up = hasattr(lr_net, "out_upsample")                       # BiSeNetOutput: head -> nn.Upsample(x8, align_corners=False)
     if fused_up:
         lo, _ = lr_net.phase2_warp(feat, list(ref_ps), mv_qs, upsample=False)

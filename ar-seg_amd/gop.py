@@ -12,6 +12,13 @@ mandates on top of it.  Two plans, both with ONE exchange
   HR forward and broadcasts ``ref_p``; the ``gop-1`` non-keyframes are dealt round-robin over the ranks (11 frames over 8
   ranks: 2 + 1, the imbalance SURVEY.md section 8e notes).
 
+* **neighbor** (``deal="neighbor"``; round 6, the same sharding idea with xGMI's point-to-point links in mind): frames are dealt in
+  CONTIGUOUS runs that straddle a GOP boundary -- rank ``r`` takes the second half of each GOP it owns (d = 6..11) and the first half of
+  the next GOP (d = 1..5), so every GOP's frames are still sharded over two GPUs, but a rank needs exactly ONE foreign keyframe
+  feature per owned GOP: one point-to-point send to rank ``r-1`` and one receive from rank ``r+1`` (134 MB inbound per GOP for the
+  PSPNet feature, over one direct link, against 7 x 134 MB inbound from an all-gather whose round-robin deal makes every rank's 11
+  frames span all eight GOPs).  Same work per rank, bit-equal outputs; ``bench.py --gpus N`` prints it beside the other plans.
+
 * **local** (``local=True``; the zero-communication comparison line of SURVEY.md section 8e, not the mandated design): rank ``g`` keeps
   GOP ``g`` whole -- its own keyframe and that GOP's ``gop-1`` non-keyframes -- and nothing is exchanged.  Same work per rank as the
   batched plan, so the two rates differ by exactly what the exchange costs (``bench.py --gpus N`` prints both).
@@ -51,6 +58,18 @@ def keyframe_owner(g: int, world: int) -> int:
     return g % world
 
 
+def neighbor_plan(n_gops: int, gop: int, world: int) -> List[List[Tuple[int, int]]]:
+    """The contiguous-run deal: plan[rank] = for each GOP g the rank owns, the second half of g (d > (gop-1)//2 ... ) followed by the first
+    half of GOP (g+1) % n_gops (owned by rank+1).  Every frame exactly once, gop-1 frames per owned GOP per rank."""
+    first = (gop - 1) // 2                 # frames d = 1..first of a GOP go to the previous GOP's owner
+    plan: List[List[Tuple[int, int]]] = [[] for _ in range(world)]
+    for g in range(n_gops):
+        r = keyframe_owner(g, world)
+        plan[r] += [(g, d) for d in range(first + 1, gop)]
+        plan[r] += [((g + 1) % n_gops, d) for d in range(1, first + 1)]
+    return plan
+
+
 class GopRunner:
     """key_fn(keyframe) -> ref_p tensor; nonkey_fn(ref_p, frame, mv) -> output.
 
@@ -59,7 +78,10 @@ class GopRunner:
     Returns {(gop index, d): output} for this rank's frames.
     """
 
-    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None, local: bool = False, loopback: bool = False):
+    def __init__(self, key_fn: Callable, nonkey_fn: Callable, n_gops: int, gop: int = 12, group=None, local: bool = False, loopback: bool = False,
+                 deal: str = "round_robin"):
+        if deal not in ("round_robin", "neighbor"):
+            raise ValueError(f"deal must be 'round_robin' or 'neighbor', got {deal!r}")
         self.key_fn, self.nonkey_fn = key_fn, nonkey_fn
         self.n_gops, self.gop, self.group = n_gops, gop, group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -78,7 +100,9 @@ class GopRunner:
         if not self.single_gop and n_gops % self.world:
             raise ValueError(f"n_gops ({n_gops}) must be a multiple of the world size ({self.world})")
         self.my_gops = [g for g in range(n_gops) if keyframe_owner(g, self.world) == self.rank]
-        self.plan = ([(g, d) for g in self.my_gops for d in range(1, gop)] if self.local else frame_plan(n_gops, gop, self.world)[self.rank])
+        self.neighbor = deal == "neighbor" and not self.local and not self.single_gop
+        self.plan = ([(g, d) for g in self.my_gops for d in range(1, gop)] if self.local else
+                     neighbor_plan(n_gops, gop, self.world)[self.rank] if self.neighbor else frame_plan(n_gops, gop, self.world)[self.rank])
         # gather buffer (1 GB at world 8 for the PSPNet feature) and side stream, one pair PER LAUNCH STREAM: steps rotated over several
         # streams run concurrently, and a single buffer would be overwritten by the next step's collective while this step's warp +
         # CReFF still read it (the side stream's wait on ITS launch stream orders a buffer's reuse behind its previous consumer)
@@ -112,6 +136,8 @@ class GopRunner:
             return list(local_refs)
         if self.local:                    # whole GOPs per rank: the features never leave the rank (indexed by gop like the other plans)
             return dict(zip(self.my_gops, local_refs))
+        if self.neighbor:
+            return self._exchange_neighbor(local_refs)
         if self.single_gop:
             if self.rank == 0:
                 buf = local_refs[0].contiguous()
@@ -126,6 +152,26 @@ class GopRunner:
         flat = self._buffer(stacked)
         dist.all_gather_into_tensor(flat, stacked.contiguous(), group=self.group)        # concatenation along dim 0
         return self._index(flat.view((self.world, per_rank) + tuple(stacked.shape[1:])), per_rank)
+
+    def _exchange_neighbor(self, local_refs: Sequence[torch.Tensor]) -> Dict[int, torch.Tensor]:
+        """One point-to-point step: this rank's keyframe features go to rank-1 (which holds the first halves of those GOPs' successors...
+        precisely: rank r-1 processes the first half of every GOP rank r owns), the features of rank+1's GOPs arrive here.  Grouped
+        send/recv (ncclSend / ncclRecv on RCCL: one direct xGMI link each way); world 1 (loopback): the successor GOP is local."""
+        refs: Dict[int, torch.Tensor] = dict(zip(self.my_gops, local_refs))
+        if self.world == 1:
+            return refs
+        nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
+        stacked = (torch.stack(list(local_refs)) if len(local_refs) > 1 else local_refs[0].unsqueeze(0)).contiguous()
+        inbox = self._buffer(stacked, replicas=1)
+        ops_ = [dist.P2POp(dist.isend, stacked, prv, self.group), dist.P2POp(dist.irecv, inbox, nxt, self.group)]
+        if self.world == 2 and self.rank == 1:      # (two ranks: both peers are the same process -- post the pair in the same order on both sides)
+            ops_.reverse()
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+        theirs = [g for g in range(self.n_gops) if keyframe_owner(g, self.world) == nxt]
+        for i, g in enumerate(theirs):
+            refs[g] = inbox[i]
+        return refs
 
     # ------------------------------------------------------------------ schedules
     def run(self, keyframes, frames, mvs, like: Optional[torch.Tensor] = None):
@@ -170,10 +216,15 @@ class GopRunner:
             feat = phase1_fn(frames_stacked)                        # overlaps the collective
             if ev:
                 ev[3].record()
-                nbytes = sum(r.numel() * r.element_size() for r in local_refs)
+                # bytes of ONE keyframe feature set as this rank sees it: from what the exchange returned (ranks that own no keyframe -- the
+                # single-GOP plan's receivers -- have no local_refs)
+                r0 = refs[0] if not isinstance(refs, dict) else next(iter(refs.values()))
+                nbytes = r0.numel() * r0.element_size() * max(1, len(local_refs))
                 self.timing.append((ev, nbytes))
+                if len(self.timing) > 4096:          # bounded: a long run with timing left on keeps the most recent steps
+                    del self.timing[:2048]
             main.wait_stream(side)
-            for r in refs:
+            for r in (refs.values() if isinstance(refs, dict) else refs):
                 r.record_stream(main)
         else:
             refs = self.exchange(local_refs, like)
@@ -197,11 +248,12 @@ class GopRunner:
         p1 = [e[2].elapsed_time(e[3]) for e, _ in self.timing]
         lag = [e[3].elapsed_time(e[1]) for e, _ in self.timing]           # > 0: the collective finished AFTER phase 1 (exposed by that much)
         sent = self.timing[0][1]
-        peers = self.world - 1
+        peers = 1 if self.neighbor else self.world - 1
         recv = sent * peers if not self.single_gop else (0 if self.rank == 0 else sent)
         n = len(ex)
         ex_ms = sum(ex) / n
-        return {"steps": n, "plan": "broadcast" if self.single_gop else "all_gather", "exchange_ms": ex_ms, "exchange_ms_max": max(ex),
+        self.timing = []                  # the events are consumed: the next call reports the steps recorded from here on
+        return {"steps": n, "plan": "broadcast" if self.single_gop else "neighbor_sendrecv" if self.neighbor else "all_gather", "exchange_ms": ex_ms, "exchange_ms_max": max(ex),
                 "phase1_ms": sum(p1) / n, "bytes_sent_per_rank": sent, "bytes_received_per_rank": recv,
                 "exchange_GBps_in": recv / (ex_ms * 1e-3) / 1e9 if ex_ms > 0 else None,
                 "exposed_ms": sum(max(v, 0.0) for v in lag) / n, "hidden_behind_phase1": all(v <= 0.0 for v in lag)}

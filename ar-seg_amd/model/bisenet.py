@@ -242,10 +242,13 @@ class _BiSeBase(HipModule):
         N, C, H, W = x.shape
         return self._trunk_nhwc4(ops.frame_ingest(x, H, W, self.storage_dtype))
 
-    def phase1_nhwc4(self, x4):
+    def phase1_nhwc4(self, x4, aux=True):
         """forward_phase1 on an NHWC4 frame: same outputs as the reference (aux heads included in 'train'
-        aux_mode, bisenet.py:557-559) with the CReFF input left in NHWC."""
+        aux_mode, bisenet.py:557-559) with the CReFF input left in NHWC.  ``aux=False`` (the build's fast paths, which read
+        ``[-1]`` only as evaluation.py:190-191 does): the two training-only aux heads and their x8 / x16 upsamples are not evaluated."""
         cp8, cp16, mid = self._trunk_nhwc4(x4)
+        if not aux:
+            return (mid,)
         if self.aux_mode == 'train':
             return self.conv_out16.forward_nhwc(cp8), self.conv_out32.forward_nhwc(cp16), mid
         if self.aux_mode == 'eval':
@@ -266,6 +269,14 @@ class _BiSeBase(HipModule):
             ops.resize_nhwc(self.sp.forward_nhwc(x4), ch, cw, _lib.BILINEAR, True, out=fcat[..., :128])
         feat_fuse = self.ffm.forward_nhwc(fcat)
         return feat_cp8, feat_cp16, self.feat_conv_out.forward_nhwc(feat_fuse)
+
+    def forward_keyframe(self, x):
+        """The keyframe's pass as the video pipeline needs it (evaluation.py:173-174 reads ``[-1]``, the frame's own segmentation is ``[0]``):
+        -> (logits NCHW at frame resolution, middle feature NHWC).  Same arithmetic as ``forward``; the training-only aux heads
+        (bisenet.py:455-457) and their x8 / x16 upsamples are not evaluated."""
+        self._check_inference()
+        _, _, mid = self._trunk_nhwc(x)
+        return self.conv_out.head_nhwc(mid), mid
 
     def _forward_normal(self, x):
         self._check_inference()

@@ -106,14 +106,17 @@ class _PSPBase(HipModule):
         N, C, H, W = x.shape
         return self.phase1_nhwc4(ops.frame_to_nhwc4(x, H, W))
 
-    def phase1_nhwc4(self, x4):
-        """The backbone on an NHWC4 frame (pspnet.py:198-217): -> (aux logits [N,n_cls], p NHWC)."""
+    def phase1_nhwc4(self, x4, aux=True):
+        """The backbone on an NHWC4 frame (pspnet.py:198-217): -> (aux logits [N,n_cls], p NHWC).  ``aux=False`` (the build's fast paths, which
+        read ``[-1]`` only as evaluation.py:190-191 does): the training-only auxiliary classifier (pspnet.py:92-94) is not evaluated -> (None, p)."""
         N, H, W, _ = x4.shape
         f, class_f = self.feats.forward_nhwc(x4)
         p = self.psp.forward_nhwc(f)            # drop_1 / drop_2: identity in eval
         p = self.up_1.forward_nhwc(p, out_split=True)
         p = self.up_2.forward_nhwc(p)
         p = self.up_3.forward_nhwc(p)
+        if not aux:
+            return None, p
         pk = self.packed()
         aux = ops.global_reduce(class_f, _lib.REDUCE_MAX)
         aux = ops.conv2d(ops.conv2d(aux, pk["cls0"]), pk["cls2"])
@@ -132,6 +135,14 @@ class _PSPBase(HipModule):
         N, C, H, W = x.shape
         aux, p = self._trunk_nhwc(x)
         return self._final(p, H, W), aux, ops.as_nchw(p)
+
+    def forward_keyframe(self, x):
+        """The keyframe's pass as the video pipeline needs it (evaluation.py:173-174 reads ``[-1]``, the frame's own segmentation is ``[0]``):
+        -> (log-probs NCHW, p NHWC).  Same arithmetic as ``forward``; the training-only auxiliary classifier output is not evaluated."""
+        self._check_inference()
+        N, C, H, W = x.shape
+        _, p = self.phase1_nhwc4(ops.frame_to_nhwc4(x, H, W), aux=False)
+        return self._final(p, H, W), p
 
 
 class PSPNet(_PSPBase):

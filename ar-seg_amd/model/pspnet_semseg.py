@@ -82,8 +82,9 @@ class _SemsegBase(HipModule):
                 "aux0": PackedConv.from_modules(self.aux[0], self.aux[1], _lib.ACT_RELU, device=device),
                 "auxh": PackedHead(self.aux[4], device)}
 
-    def phase1_nhwc4(self, x4):
-        """NHWC4 frame -> (x_tmp = layer3 output NHWC [N,h/8,w/8,256], p NHWC [N,h/8,w/8,512])  (pspnet_semseg.py:219-231)."""
+    def phase1_nhwc4(self, x4, aux=True):
+        """(``aux`` is accepted for symmetry with the other networks: this trunk evaluates no auxiliary output.)
+        NHWC4 frame -> (x_tmp = layer3 output NHWC [N,h/8,w/8,256], p NHWC [N,h/8,w/8,512])  (pspnet_semseg.py:219-231)."""
         pk = self.packed()
         x = ops.maxpool3x3s2(ops.conv2d(x4, pk["stem"]))
         for layer in (self.layer1, self.layer2, self.layer3):
@@ -161,6 +162,14 @@ class PSPNetWithFuse(_SemsegBase):
         N, C, H, W = x.shape
         x_tmp, p = self.phase1_nhwc4(ops.frame_to_nhwc4(x, H, W))
         return ops.as_nchw(x_tmp), ops.as_nchw(p)
+
+    def forward_keyframe(self, x):
+        """The keyframe's pass as the video pipeline needs it (evaluation.py:173-174 reads ``[-1]``): -> (logits NCHW, p NHWC); the
+        training-only aux head (pspnet_semseg.py:196-199) is not evaluated."""
+        self._check_inference()
+        N, C, H, W = x.shape
+        _, p = self.phase1_nhwc4(ops.frame_to_nhwc4(x, H, W))
+        return self._logits_up(p, self.packed()["head"], H, W), p
 
     @staticmethod
     def _ref_c8(ref_p):

@@ -54,6 +54,8 @@ class Config:
     creff_seg_rows   [ARSEG_CREFF_SEG_ROWS = n]                 fixed strip segments of n rows for the rolling kernel (0: its balanced default schedule)
     creff_max_wgs    [ARSEG_CREFF_MAX_WGS = n]                  upper bound on the rolling kernel's persistent workgroups (0: one per compute unit)
     lr_subbatch      [ARSEG_LR_SUBBATCH = n]                    evaluate the LR batch of a GOP in slices of n frames (bounds the working set)
+    aux_outputs      [ARSEG_AUX_OUTPUTS = 0 | 1]                the fast paths (evaluation.alter_res_*) also evaluate the training-only auxiliary outputs that
+                     forward_phase1 returns and evaluation.py:190-191 discards (default 0: skipped; forward() / forward_phase1() always return them)
     (ARSEG_HIP_LIB = <path> selects an alternative library build; it is read by _lib before anything is loaded.)"""
     conv_math: str = "f16x3"
     conv_autotune: bool = True
@@ -71,6 +73,7 @@ class Config:
     creff_seg_rows: int = 0
     creff_max_wgs: int = 0
     lr_subbatch: int = 0
+    aux_outputs: bool = False
 
     @classmethod
     def from_env(cls):
@@ -93,7 +96,8 @@ class Config:
                 conv_range_guard={"1": "host", "0": "off"}.get(e("ARSEG_CONV_RANGE_GUARD", "device"), e("ARSEG_CONV_RANGE_GUARD", "device")),
                 conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=num("ARSEG_CREFF_TY", int, 0),
                 creff_warp_impl=e("ARSEG_CREFF_WARP_IMPL", ""), creff_seg_rows=num("ARSEG_CREFF_SEG_ROWS", int, 0),
-                creff_max_wgs=num("ARSEG_CREFF_MAX_WGS", int, 0), lr_subbatch=num("ARSEG_LR_SUBBATCH", int, 0))
+                creff_max_wgs=num("ARSEG_CREFF_MAX_WGS", int, 0), lr_subbatch=num("ARSEG_LR_SUBBATCH", int, 0),
+                aux_outputs=e("ARSEG_AUX_OUTPUTS", "0") not in ("", "0"))
         validate(dataclasses.asdict(c), source="environment")
         return c
 

@@ -218,6 +218,8 @@ def gemm_rows16(x: torch.Tensor, pc, residual=None, out: Optional[torch.Tensor] 
                         continue
                     if tm < best_t:
                         cfg, best_t = c, tm
+                if cfg is None:          #  every tile refused the shape: the caller keeps its other plan; None is never cached
+                    raise _lib.ArsegError(f"gemm_rows16: no tile configuration accepts M={M} K={cin} N={cout}")
                 _conv_plans[key] = cfg
     with tagged(lambda: (n, h, w, pc.cin, cout, 1, 1, 1, False, f"gemm16({cfg})", flops)):
         run(cfg, record)
@@ -576,13 +578,21 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
                 except _lib.ArsegError:
                     pass
             _conv_plans[key] = plan
+        #  the plan key holds the shape, not the alignment / row pitch of `out` and `residual`: a later call with a channel-slice
+        # view the LDS-DMA kernel refuses (EINVAL) falls back to the library's heuristic instead of raising
         if plan == "rows":
             if igemm3_enabled(x) and rows_eligible(pc, Cin, _lib.ROWS_BF16):
-                return conv3x3_rows(pad_rows(x, pc.dil), pc, residual, out=out)
+                try:
+                    return conv3x3_rows(pad_rows(x, pc.dil), pc, residual, out=out)
+                except _lib.ArsegError:
+                    pass
             plan = (0, 0)                      # the route was switched off after the plan was cached: the library's heuristic
         if plan == "gemm16":
             if igemm3_enabled(x) and d.in_ld == Cin:
-                return gemm_rows16(x, pc, residual, out)
+                try:
+                    return gemm_rows16(x, pc, residual, out)
+                except _lib.ArsegError:
+                    pass
             plan = (0, 0)
         d.tile_cfg, d.split_k = plan
     flops16 = 2 * N * Ho * Wo * pc.cout * pc.R * pc.S * pc.cin

@@ -7,13 +7,16 @@
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): PSPNet-18, keyframe HR branch at
 512x1024, 11 non-keyframes per GOP through the LR branch (0.5x -> 256x512 backbone) + CReFF at 512x1024, fp32.
 
-A "step" is one GOP per rank, i.e. one pass of the hot path over one batch of synthetic input:
-    keyframe HR forward -> (N > 1: RCCL all-gather of ref_p) -> 11 x [frame downscale + NHWC ingest, LR backbone,
+A "step" is one pass of the hot path over one batch of synthetic input = `--streams` (default 6) independent GOP-12 clips per rank, which is what is
+in flight at a time.  Per clip (a "GOP step"):
+    keyframe HR forward -> (N > 1: RCCL exchange of ref_p) -> 11 x [frame downscale + NHWC ingest, LR backbone,
     MV resize + warp, fused CReFF + classifier + log-softmax]
-All inputs (frames, int16 MV maps, weights) are resident in HBM before the timed region.  `value` counts the
-non-keyframes only, while the keyframe's HR forward and the exchange are inside the timed region (nothing skipped).
-Consecutive GOPs are independent; `--streams` of them (default 6) are in flight at a time, each on its own HIP stream (N = 1: one captured
-HIP graph per lane, arseg_amd/executor.py), and exactly K steps are enqueued and completed inside the timed region.
+Each clip of the batch runs on its own HIP stream (N = 1: one captured HIP graph per lane, arseg_amd/executor.py, one replay of every lane per step);
+exactly K steps are enqueued and completed inside the timed region (`ms_per_step` = one such pass, `ms_per_gop_step` = per clip -- the unit rounds 1-5
+called a step).  All inputs (frames, int16 MV maps, weights) are resident in HBM before the timed region.  `value` counts the non-keyframes only, while
+the keyframe's HR forward (with the keyframe's own segmentation output) and the exchange are inside the timed region.  Not evaluated by default:
+the training-only auxiliary outputs that forward() / forward_phase1() return and evaluation.py:173-174,190-191 discard (PSPNet's aux classifier,
+BiSeNet's two aux heads with their x8 / x16 upsamples); `--reference-outputs` evaluates them too (printed as `value_reference_outputs` on the headline line).
 
 Arithmetic: fp32 tensors end to end.  The convolution GEMMs are evaluated on the fp16 matrix cores with every fp32 operand
 split into hi + lo fp16 (22 significant bits) and three MFMAs per product, fp32 accumulation (`--conv-math f16x3`, default;
@@ -44,7 +47,8 @@ import torch
 import torch.distributed as dist
 
 GOP = 12
-MIN_TIMED_S = 1.0          # the timed region is extended (whole multiples of --steps) until it lasts at least this long
+MIN_TIMED_S = 0.4          # a timed region shorter than this is repeated with a whole multiple of --steps (flagged in `steps_note`); the default
+                           # and the driver's `--steps 20` last longer (a step = `--streams` GOP steps in flight at a time, see the docstring)
 # headline workload = BASELINE.json configs[1]; "psp2k" = the same network with the 512x1024 *non-key* reading of the metric
 # (SURVEY.md section 8 preamble); "bise" = configs[2] (BiSeNet-18, Cityscapes sizes) measured in fp32 --
 # the bf16 MFMA conv path that config names is not built yet, so it is an extra, not the headline.
@@ -79,6 +83,44 @@ PEAK_F16_MFMA_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 
 
+def measure_peaks(dev):
+    """the on-box denominators beside the datasheet ones -- a stream copy (1 GiB, 16-byte accesses, best of 5 launches by
+    HIP events: read + write bytes / time) and an MFMA issue loop (every wave of a full-chip launch issues independent v_mfma_f32_32x32x16_f16,
+    no memory traffic; best of 5).  A few milliseconds, once per bench run."""
+    import ctypes
+
+    from arseg_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    dst = torch.empty(n, dtype=torch.uint8, device=dev)
+    scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+    flops = ctypes.c_double(0.0)
+
+    def best(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            e1.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e-3)
+        return min(ts)
+
+    t_copy = best(lambda: _lib.check(lib.arseg_peak_stream_copy(src.data_ptr(), dst.data_ptr(), n, st), "peak_stream_copy"))
+    t_mfma = best(lambda: _lib.check(lib.arseg_peak_mfma_f16(scratch.data_ptr(), 4096, ctypes.byref(flops), st), "peak_mfma_f16"))
+    del src, dst
+    return {"hbm_stream_copy_GBps": 2.0 * n / t_copy / 1e9, "mfma_f16_dense_TFLOPs": flops.value / t_mfma / 1e12,
+            "datasheet": {"hbm_GBps": PEAK_HBM_GBS, "mfma_f16_dense_TFLOPs": PEAK_F16_MFMA_TFLOPS, "mfma_f32_TFLOPs": PEAK_FP32_MFMA_TFLOPS},
+            "how": "arseg_peak_stream_copy: 1 GiB copied with 16-byte accesses, (read + write bytes) / best of 5 launches; arseg_peak_mfma_f16: 4 waves per SIMD, "
+                   "4096 x 8 independent v_mfma_f32_32x32x16_f16 per wave on constant operands (no memory traffic; an upper bound -- "
+                   "random-data GEMMs draw more power and clock lower), best of 5; HIP events on the launch stream"}
+
+
 def build_nets(dev, cfg, to_device=True):
     from arseg_amd import synth
     from arseg_amd.model import BiSeNetV1, BiSeNetV1WithFuse, PSPNet, PSPNetWithFuse, pspnet_semseg
@@ -105,18 +147,21 @@ def build_nets(dev, cfg, to_device=True):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=9)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the (slow) CPU oracle leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel event pass")
     ap.add_argument("--no-variants", action="store_true", help="skip the short runs of the other single-GPU BASELINE shapes (psp2k, bise_bf16, bise03_fp16)")
-    ap.add_argument("--variant-steps", type=int, default=9)
+    ap.add_argument("--variant-steps", type=int, default=2)
     ap.add_argument("--conv-layers", metavar="FILE", help="also write the per-layer conv table (shape, plan, us, TFLOP/s, fraction of the MFMA peak) as JSON")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="psp", help="psp = the headline workload (BASELINE configs[1])")
     ap.add_argument("--gops-per-rank", type=int, default=1, help="GOPs per rank per step (experiment: a larger LR batch per launch sequence; 1 = one GOP-12 clip per GPU as BASELINE configs[1] says)")
-    ap.add_argument("--plan", choices=["both", "exchange", "local"], default="both",
-                    help="N > 1: `value` is always the mandated exchange plan; both / local also time SURVEY 8e's zero-communication comparison plan "
-                         "(whole GOP per rank) and print it as plans.local")
+    ap.add_argument("--plan", choices=["both", "exchange", "local", "neighbor"], default="both",
+                    help="N > 1: `value` is always the mandated exchange plan (round-robin deal + all-gather); both (= all) / local / neighbor also time SURVEY 8e's "
+                         "zero-communication comparison plan (whole GOP per rank, plans.local) and the contiguous-run deal with one neighbour send / receive (plans.neighbor)")
+    ap.add_argument("--reference-outputs", action="store_true",
+                    help="also evaluate the training-only auxiliary outputs of forward() / forward_phase1() that evaluation.py:173-174,190-191 discard "
+                         "(PSPNet: the aux classifier; BiSeNet: the two aux heads and their x8 / x16 upsamples).  Default: the fast paths skip them")
     ap.add_argument("--streams", type=int, default=6, help="HIP streams the GOP steps are rotated over (independent GOPs overlap)")
     ap.add_argument("--joined-graph", action="store_true", help="capture the lanes into ONE graph with a join per replay (the round-2 executor) instead of one graph per lane")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step eagerly instead of replaying the captured HIP graph (N = 1 only)")
@@ -159,27 +204,50 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     result = run_config(args, args.config, args.steps, args.warmup, world, rank, dev, backend, full=True)
+    if rank == 0:
+        try:
+            pk = measure_peaks(dev)
+            result["peaks_measured"] = pk
+            # the two graded fractions once more against the on-box peaks
+            if "roofline" in result and result["roofline"].get("achieved"):
+                result["roofline"]["frac_of_measured_copy"] = result["roofline"]["achieved"] / pk["hbm_stream_copy_GBps"]
+            rc = result.get("roofline_conv")
+            if rc and rc.get("achieved") and rc.get("peak") == PEAK_F16_MFMA_TFLOPS:
+                rc["frac_of_measured_mfma"] = rc["achieved"] / pk["mfma_f16_dense_TFLOPs"]
+                rc["mfma_issue_frac_of_measured"] = rc["mfma_issue_frac"] * PEAK_F16_MFMA_TFLOPS / pk["mfma_f16_dense_TFLOPs"]
+        except Exception as exc:          # a measurement aid must never take the line down
+            result["peaks_measured"] = {"error": repr(exc)}
     # ---- the other single-GPU BASELINE shapes, driver-timed in the same line (short runs)
     if world == 1 and args.config == "psp" and not args.no_variants and not args.loopback:
         result["variants"] = {}
-        for name in ("psp_f32", "psp2k", "bise_bf16", "bise03_fp16"):
+        for name in ("psp_f32", "psp_reference_outputs", "psp2k", "bise_bf16", "bise03_fp16"):
             try:
-                if name == "psp_f32":          # the headline workload with the reference's own arithmetic: fp32 MFMA.  conv_frac_mfma = the REFERENCE's
-                    # direct-conv FLOPs / time / 157 TF exceeds 1 because Winograd, the folded pyramid and the tap-decomposed upsample convs
-                    # execute fewer products than the reference counts; conv_mfma_issue_frac = the executed GEMM FLOPs against the same peak
+                if name == "psp_f32":          # the headline workload with the reference's own arithmetic: fp32 MFMA
                     a32 = argparse.Namespace(**{**vars(args), "conv_math": "f32"})
-                    r = run_config(a32, "psp", args.variant_steps, 3, world, rank, dev, backend, full=False)
+                    r = run_config(a32, "psp", args.variant_steps, 1, world, rank, dev, backend, full=False)
+                elif name == "psp_reference_outputs":      # the headline workload with the training-only auxiliary outputs evaluated as well
+                    if args.reference_outputs:
+                        continue
+                    aro = argparse.Namespace(**{**vars(args), "reference_outputs": True})
+                    r = run_config(aro, "psp", args.variant_steps, 1, world, rank, dev, backend, full=False)
                 else:
-                    r = run_config(args, name, args.variant_steps, 3, world, rank, dev, backend, full=False)
+                    r = run_config(args, name, args.variant_steps, 1, world, rank, dev, backend, full=False)
+                rc = r.get("roofline_conv", {})
                 result["variants"][name] = {
                     "workload": r["config"]["workload"], "value": r["value"], "unit": r["unit"], "dtype": r["dtype"], "steps": r["steps"],
-                    "conv_math": r["conv_math"], "conv_peak_tflops": r.get("roofline_conv", {}).get("peak"),
-                    "conv_mfma_issue_frac": r.get("roofline_conv", {}).get("mfma_issue_frac"),
-                    "ms_per_step": r["ms_per_step"],
+                    "output": r["config"].get("output"),
+                    "conv_math": r["conv_math"], "conv_peak_tflops": rc.get("peak"),
+                    "conv_frac_mfma": rc.get("frac"), "conv_mfma_issue_frac": rc.get("mfma_issue_frac"),
+                    "conv_reference_flops_over_peak": rc.get("reference_flops_over_peak"),
+                    "ms_per_step": r["ms_per_step"], "ms_per_gop_step": r["ms_per_gop_step"],
                     "creff_stage_frac_hbm": r.get("roofline", {}).get("frac"), "creff_stage_kernel": r.get("roofline", {}).get("kernel"),
-                    "conv_frac_mfma": r.get("roofline_conv", {}).get("frac"), "parity": r.get("parity")}
+                    "creff_stage_traffic_over_algorithmic": r.get("roofline", {}).get("traffic_over_algorithmic"),
+                    "parity": r.get("parity")}
             except Exception as exc:      # a variant must never take the headline line down with it
                 result["variants"][name] = {"error": repr(exc)}
+        ops.configure(aux_outputs=bool(args.reference_outputs))
+    if "variants" in result and "value" in result["variants"].get("psp_reference_outputs", {}):
+        result["value_reference_outputs"] = result["variants"]["psp_reference_outputs"]["value"]
     if "variants" in result and "value" in result["variants"].get("psp_f32", {}):
         # side by side at the top level: `value` is fp32 tensors with f16x3 conv arithmetic (22-bit operands, fp32 accumulate);
         # this is the same workload on the fp32 MFMA -- the reference's own arithmetic
@@ -206,6 +274,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
 
     _lib.load()
     ops.set_conv_math(args.conv_math)
+    ops.configure(aux_outputs=bool(args.reference_outputs))
     cfg = CONFIGS[config]
     _log(f"config {config}: building nets and clips")
     SCALE = cfg.get("scale", 0.5)
@@ -220,7 +289,10 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
 
     # ---- synthetic batch: `world` GOPs; this rank owns keyframe `rank` and 11 round-robin non-keyframes
     def key_fn(key_img):
-        return ops.to_nhwc(hr(key_img)[-1])[0]                        # ref_p, NHWC [Hp,Wp,C]
+        # the keyframe's own segmentation + ref_p (NHWC [Hp,Wp,C]); --reference-outputs: also the training-only auxiliary outputs forward() returns
+        if args.reference_outputs:
+            return ops.to_nhwc(hr(key_img)[-1])[0]
+        return hr.forward_keyframe(key_img)[-1][0]
 
     def nonkey_fn(ref_p, img, mvq):
         out, p_c8 = ev.alter_res_step_fast(lr, ref_p.unsqueeze(0), img, mvq, SCALE)
@@ -229,8 +301,12 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     GPR = max(1, int(args.gops_per_rank))          # GOPs per rank per step (1 = BASELINE's clip per GPU; > 1: an experiment knob, the batch of a step grows)
     multi = world > 1 or getattr(args, "loopback", False)      # the step of the multi-rank path (at N = 1: the RCCL loopback check)
     runner = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP, loopback=getattr(args, "loopback", False))
+    # (round 6) the contiguous-run deal: a rank's frames straddle ONE GOP boundary, one send / receive between ring neighbours instead of the all-gather
+    runner_n = None
+    if world > 1 and full and args.plan in ("both", "neighbor"):
+        runner_n = GopRunner(key_fn, nonkey_fn, n_gops=world * GPR, gop=GOP, deal="neighbor")
     clips = {}
-    needed = set(runner.my_gops) | {g for g, _ in runner.plan}
+    needed = set(runner.my_gops) | {g for g, _ in runner.plan} | ({g for g, _ in runner_n.plan} if runner_n is not None else set())
     for g in sorted(needed):
         clips[g] = synth.make_clip(g, H, W, gop=GOP, mean=mean, std=std)
     keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
@@ -266,6 +342,11 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         fl = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner_l.plan]).to(dev)
         ml = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in runner_l.plan]).to(dev)
         step_local = make_step(runner_l, fl, ml)
+    step_neigh = None
+    if runner_n is not None:
+        fn_ = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner_n.plan]).to(dev)
+        mn_ = torch.cat([torch.from_numpy(clips[g]["mv"][d:d + 1]) for g, d in runner_n.plan]).to(dev)
+        step_neigh = make_step(runner_n, fn_, mn_)
 
     # Consecutive GOPs are independent: rotating them over a few HIP streams lets the MFMA-bound backbone convs of one GOP
     # run beside the VALU/LDS-bound warp + CReFF kernels of another.  Every step is fully executed; the timed region is
@@ -281,18 +362,20 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             gop_graph = GopGraph([step] * len(streams), warmup=1, independent=not args.joined_graph)
         torch.cuda.synchronize()
 
+    L = len(streams)                     # GOP steps (GOP-12 clips per rank) in flight at a time = what ONE bench step enqueues
+
     def run_steps(k, step=step):
+        """k bench steps = k passes over the batch of L independent GOP clips per rank: one replay of the lane graphs each (N = 1), or L GOP
+        steps rotated over the L streams (eager: N > 1, --no-graph, the comparison plans)."""
         out = None
-        i = 0
         if gop_graph is not None and step is step_main:
             with torch.cuda.stream(streams[0]):
-                while i + gop_graph.lanes <= k:
+                for _ in range(k):
                     out = gop_graph.replay(join=False)[0]      # (the timed region ends in a device-wide synchronize)
-                    i += gop_graph.lanes
-        while i < k:
-            with torch.cuda.stream(streams[i % len(streams)]):
+            return out
+        for i in range(k * L):
+            with torch.cuda.stream(streams[i % L]):
                 out = step()
-            i += 1
         return out
 
     def timed_region(k, step=step):
@@ -318,7 +401,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     _log("timed region")
     steps_requested = steps
     elapsed, outs = timed_region(steps)
-    requested_run = {"steps": steps, "timed_s": elapsed, "value": world * GPR * (GOP - 1) * steps / elapsed}      # the run the command line asked for, as timed
+    requested_run = {"steps": steps, "timed_s": elapsed, "value": world * GPR * (GOP - 1) * L * steps / elapsed}      # the run the command line asked for, as timed
     steps_note = None
     min_s = MIN_TIMED_S if full else 0.3 * MIN_TIMED_S          # variant lines: a shorter window, still far above launch jitter
     if elapsed < min_s:
@@ -327,7 +410,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         steps = steps_requested * int(math.ceil(1.05 * min_s / max(elapsed, 1e-6)))
         elapsed, outs = timed_region(steps)
         steps_note = (f"--steps {steps_requested} lasted {requested_run['timed_s']:.3f} s ({requested_run['value']:.0f} frames/s, `requested_run`): shorter than the "
-                      f"{min_s:.1f} s this bench trusts, so `value` / `steps` / `ms_per_step` are from a second region of {steps} = {steps // steps_requested} x "
+                      f"{min_s:.2f} s this bench trusts, so `value` / `steps` / `ms_per_step` are from a second region of {steps} = {steps // steps_requested} x "
                       f"{steps_requested} steps, timed the same way (barrier + synchronize on both sides, max over ranks)")
     # N > 1: the rolling CReFF kernel's persistent workgroups hold EVERY compute unit for ~1.7 ms at a time, and an RCCL kernel that cannot get a
     # compute unit on one GPU keeps its peers' RCCL kernels spinning on theirs.  Whether leaving a few compute units to the collective pays cannot
@@ -337,11 +420,11 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     reserve = None
     if world > 1 and full and not fused_tail and ops.config.creff_max_wgs == 0:
         cus = torch.cuda.get_device_properties(dev).multi_processor_count
-        all_cus = {"creff_max_wgs": 0, "value": world * GPR * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps}
+        all_cus = {"creff_max_wgs": 0, "value": world * GPR * (GOP - 1) * L * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps}
         ops.configure(creff_max_wgs=max(1, cus - 16))
-        run_steps(max(2, len(streams)))
+        run_steps(1)
         r_el, r_outs = timed_region(steps)
-        res_cus = {"creff_max_wgs": max(1, cus - 16), "value": world * GPR * (GOP - 1) * steps / r_el, "ms_per_step": 1e3 * r_el / steps}
+        res_cus = {"creff_max_wgs": max(1, cus - 16), "value": world * GPR * (GOP - 1) * L * steps / r_el, "ms_per_step": 1e3 * r_el / steps}
         if r_el < elapsed:
             elapsed, outs = r_el, r_outs
         else:
@@ -351,18 +434,26 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                            "kernels; `value` is the faster one"}
     plans = None
     if step_local is not None:
-        run_steps(max(2, warmup // 2), step_local)
+        run_steps(max(1, warmup // 2), step_local)
         l_el, _ = timed_region(steps, step_local)
-        plans = {"exchange": {"value": world * GPR * (GOP - 1) * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
+        plans = {"exchange": {"value": world * GPR * (GOP - 1) * L * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps,
                               "what": "the mandated plan: frames dealt round-robin, one all-gather of the keyframe features per step on a side stream under phase 1"},
-                 "local": {"value": world * GPR * (GOP - 1) * steps / l_el, "ms_per_step": 1e3 * l_el / steps,
+                 "local": {"value": world * GPR * (GOP - 1) * L * steps / l_el, "ms_per_step": 1e3 * l_el / steps,
                            "what": "SURVEY 8e comparison line: whole GOP per rank, no exchange (same kernels, same work per rank)"},
                  "exchange_cost_frac": 1.0 - l_el / elapsed, "unit": "frames/s", "steps": steps}
+    if step_neigh is not None:
+        run_steps(max(1, warmup // 2), step_neigh)
+        n_el, _ = timed_region(steps, step_neigh)
+        plans = plans or {"exchange": {"value": world * GPR * (GOP - 1) * L * steps / elapsed, "ms_per_step": 1e3 * elapsed / steps}, "unit": "frames/s", "steps": steps}
+        plans["neighbor"] = {"value": world * GPR * (GOP - 1) * L * steps / n_el, "ms_per_step": 1e3 * n_el / steps,
+                             "what": "frames dealt in contiguous runs that straddle one GOP boundary (rank r: d = 6..11 of its GOP, d = 1..5 of the next): every GOP still "
+                                     "sharded over two GPUs, ONE keyframe feature in and one out per rank and step (grouped send / receive between ring neighbours "
+                                     "over one xGMI link) instead of the all-gather's world-1; bit-equal outputs"}
     exchange_stats = None
     if multi and full and not fused_tail:
         # self-diagnosing exchange: a few more steps with HIP events around the side-stream collective and around phase 1
         runner.enable_timing()
-        run_steps(2 * len(streams))
+        run_steps(2)
         exchange_stats = runner.exchange_stats()
         runner.enable_timing(False)
         if exchange_stats is not None:          # every rank's view, worst case first: the slowest link decides the step
@@ -377,14 +468,14 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
     eager = None
     if full and gop_graph is not None:
         g_keep, gop_graph = gop_graph, None
-        run_steps(len(streams))
-        e_steps = max(len(streams), int(math.ceil(0.5 / max(elapsed / steps, 1e-6))))
+        run_steps(1)
+        e_steps = max(1, int(math.ceil(0.5 / max(elapsed / steps, 1e-6))))
         e_el, _ = timed_region(e_steps)
         gop_graph = g_keep
-        eager = {"value": world * GPR * (GOP - 1) * e_steps / e_el, "unit": "frames/s", "ms_per_step": 1e3 * e_el / e_steps, "steps": e_steps,
+        eager = {"value": world * GPR * (GOP - 1) * L * e_steps / e_el, "unit": "frames/s", "ms_per_step": 1e3 * e_el / e_steps, "steps": e_steps,
                  "note": "the same step enqueued eagerly from Python (no HIP graph), as every rank does at N > 1"}
 
-    nonkey_per_step = world * GPR * (GOP - 1)
+    nonkey_per_step = world * GPR * (GOP - 1) * L
     result = {
         "metric": {"psp": "non-keyframe frames/sec (backbone+CReFF) at 512x1024",
                    "psp2k": "non-keyframe frames/sec (backbone+CReFF), PSPNet-18 1024x2048 / LR 512x1024",
@@ -403,9 +494,17 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                                        "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
         "streams": len(streams), "executor": ("hip-graph replay (%d lanes, one graph per lane on its own stream)" if not args.joined_graph else "hip-graph replay (%d GOP steps per replay on forked streams)") % len(streams) if gop_graph is not None else "eager launches",
         "config": {"workload": cfg["label"] + ", GOP-12 synthetic clip per GPU, random-init (seeded) weights" + (", fp32 tensors" if storage == "f32" else ""),
+                   "output": ("per non-keyframe: the fused argmax label map [H,W] (head -> x8 upsample -> argmax in one kernel; the [19,H,W] logits are never written), "
+                              "p [256,H/8,W/8]; per keyframe: full logits") if cfg["kind"] == "bise" else
+                             ("per non-keyframe: logits at feature resolution [n_cls,H/8,W/8] + p" if cfg["kind"] == "semseg" else
+                              "per non-keyframe: full log-probabilities [n_cls,H,W] + p [64,H,W]; per keyframe: the same"),
+                   "aux_outputs": "evaluated (--reference-outputs)" if args.reference_outputs else "skipped (training-only outputs the evaluator discards)",
                    "gop": GOP, "frame": [H, W], "lr_scale": SCALE, "n_classes": N_CLS,
                    "parallelism": f"dp{world} (frames sharded round-robin, all-gather of keyframe features)"},
-        "all_frames_per_s": world * GPR * GOP * steps / elapsed,
+        "all_frames_per_s": world * GPR * GOP * L * steps / elapsed,
+        "step_definition": f"one bench step = one pass over the batch of {L} independent GOP-12 clips per rank that are in flight at a time (one replay of the {L} lane "
+                           f"graphs at N = 1): {L} keyframe HR forwards + {L * (GOP - 1)} non-keyframes per rank; ms_per_gop_step = ms_per_step / {L}",
+        "gops_per_step_per_rank": L * GPR, "ms_per_gop_step": 1e3 * elapsed / steps / L,
     }
     if eager is not None:
         result["eager_launches"] = eager
@@ -447,9 +546,9 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
             # Found by the 2-rank rehearsal, ARSEG_DIST_BACKEND=gloo; the N > 1 line has the exchange diagnostics instead)
             if not fused_tail and not multi:
                 g_keep, gop_graph = gop_graph, None
-                run_steps(len(streams))
+                run_steps(1)
                 with ops.profile(only=("creff_warp", "creff", "warp_mvq")) as prof_instep:
-                    run_steps(3 * len(streams))
+                    run_steps(3)
                 gop_graph = g_keep
         nk = prof_nk.summary()
         ky = prof_key.summary()
@@ -483,9 +582,14 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                       "conv_igemm_kernel<BM,BN,BK,NBUF,MATH> + gemm_x3_kernel<NWM,NWN,WTM,WTN> + conv3x3_patch_kernel<BN,WM> (implicit GEMM / LDS-DMA GEMM on pre-split operands for the batched Winograd and 1x1 GEMMs / patch-resident 3x3; " +
                       {"f16x3": "3 x v_mfma_f32_32x32x16_f16 on hi/lo-split fp32 operands)", "f16": "v_mfma_f32_32x32x16_f16 on fp16-rounded operands)",
                        "f32": "v_mfma_f32_32x32x2_f32)"}[args.conv_math],
-            "bound": "mfma", "achieved": ref_tf, "peak": peak, "unit": "TFLOP/s",
-            "frac": ref_tf / peak if ref_tf else None,
-            "frac_incl_winograd_transforms": ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12 / peak if ref_flops else None,
+            # `frac`: the reference's direct-conv FLOPs over the peak of the instruction class used -- unless that exceeds what the matrix cores issue
+            # (fp32 MFMA: Winograd, the folded pyramid and the tap-decomposed upsample convs execute fewer products than the reference counts, and
+            # reference FLOPs / 157 TF comes out above 1): then the executed issue fraction is the fraction and the algorithmic figure moves to
+            # `reference_flops_over_peak` (a roofline fraction above 1 reads as a broken roofline)
+            "bound": "mfma", "achieved": ref_tf if (ref_tf and ref_tf <= mfma_mult * gemm_tf) else mfma_mult * gemm_tf, "peak": peak, "unit": "TFLOP/s",
+            "frac": (ref_tf if (ref_tf and ref_tf <= mfma_mult * gemm_tf) else mfma_mult * gemm_tf) / peak,
+            "reference_flops_over_peak": ref_tf / peak if ref_tf else None,
+            "frac_incl_winograd_transforms": min(ref_flops / ((tot_ms + wino_ms) * 1e-3) / 1e12, mfma_mult * gemm_tf) / peak if ref_flops else None,
             "mfma_issue_frac": mfma_mult * gemm_tf / peak,
             "mfma_util_pmc": traffic_db.get("conv_all_tiles", {}).get("mfma_util"),
             "traffic": conv_traffic,
@@ -540,6 +644,14 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         roll = which == "roll"
         kname = ("creff_roll_kernel<NB>" if roll else "creff_rr_kernel<NB>") if fused else ("creff_mfma_kernel<NB,TY>" if C >= 128 else "creff_kernel<7,NC,TH>")
         kt = next((v for k, v in traffic_db.get("kernels", {}).items() if k.startswith(kname.split("<")[0])), None)
+
+        def hbm_bytes(v):
+            return (2 * v["fetch_kib_avg"] + v["write_kib_avg"]) * 1024 if v and "fetch_kib_avg" in v and "write_kib_avg" in v else None
+
+        stage_traffic = hbm_bytes(kt)
+        if not fused and stage_traffic is not None:      # two launches make the stage: the MV warp's bytes count as well
+            kw = next((v for k, v in traffic_db.get("kernels", {}).items() if k.startswith("warp_mvq")), None)
+            stage_traffic = stage_traffic + hbm_bytes(kw) if hbm_bytes(kw) is not None else None
         result["roofline"] = {
             "kernel": kname + ((" (MV warp + CReFF + classifier + log-softmax in one kernel: 16-column strips walked down two rows at a time, "
                                 "key / value records of the 7x7 windows in LDS rings, producer and consumer waves overlapped)" if roll else
@@ -547,7 +659,8 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                                " (fused CReFF + classifier) behind warp_mvq_nhwc_kernel (MV warp); achieved counts both"),
             "bound": "hbm", "achieved": stage_bytes / (stage_ms * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": stage_bytes / (stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
-            "traffic": (2 * kt["fetch_kib_avg"] + kt["write_kib_avg"]) * 1024 if kt and "fetch_kib_avg" in kt and "write_kib_avg" in kt else None,
+            "traffic": stage_traffic,
+            "traffic_over_algorithmic": stage_traffic / (stage_bytes * nfr) if stage_traffic else None,
             "algorithmic_bytes_per_unit": stage_bytes, "units_per_launch": nfr, "avg_launch_ms": launch_ms, "avg_launch_ms_in_instrumented_step": step_launch_ms,
             "avg_launch_ms_dense": dense_launch_ms, "frac_dense": stage_bytes / (dense_stage_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
             "avg_launch_ms_concurrent_lanes": conc_launch_ms,
@@ -607,10 +720,14 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                 ts.append(time.perf_counter() - t1)
             return statistics.median(ts), ts
 
-        # many-core hosts: the oracle's strip-wise ops stop scaling (and collapse) far below 256 threads
+        # os.cpu_count() threads.  The oracle's 7x7 local attention runs on oracle/local_attn_ref.c's OpenMP variants (bit-equal to its
+        # scalar restatement, rows in parallel on every thread); the rest of the frame is torch CPU ops at the same thread count.  torch's own
+        # thread scaling on these small convs is not monotone on a many-core host, so the sample is timed at os.cpu_count() AND at a few smaller
+        # counts: `value` / `cores` = the fastest, `at_all_host_cores` = the os.cpu_count() figure.
         host_cores = os.cpu_count() or 1
-        ncores = min(int(os.environ.get("ARSEG_CPU_THREADS", "16")), host_cores)
+        ncores = host_cores if "ARSEG_CPU_THREADS" not in os.environ else min(int(os.environ["ARSEG_CPU_THREADS"]), host_cores)
         torch.set_num_threads(ncores)
+        cpu_ref.use_c_local_attention(ncores)
         g0, d0 = runner.plan[0]
         img = torch.from_numpy(clips[g0]["frames"][d0:d0 + 1])
         key = torch.from_numpy(clips[g0]["frames"][0:1])
@@ -630,23 +747,22 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
                 reps = (0, 1)                                                     # a variant line: one oracle pass for the parity figures
             cpu_s, samples = timed(one_frame, *reps)
             o_out, o_p, _, _ = keep["r"]
-        # SURVEY 8d asks for os.cpu_count() threads; the oracle's strip-wise ops stop scaling far below that (at 256 threads one frame does
-        # not finish in a minute), so the sample is repeated at a few thread counts and the best one is the baseline (about 10 s in all)
         sweep = {ncores: cpu_s}
         if full:
-            for nt in (32, 64):
-                if nt <= host_cores and nt != ncores:
+            for nt in (16, 32, 64, 128):
+                if nt < host_cores and nt != ncores:
                     torch.set_num_threads(nt)
+                    cpu_ref.use_c_local_attention(nt)
                     with torch.no_grad():
                         sweep[nt] = timed(one_frame, 1, 2)[0]
             best = min(sweep, key=sweep.get)
+            torch.set_num_threads(best)
+            cpu_ref.use_c_local_attention(best)
             if best != ncores:
-                torch.set_num_threads(best)
                 with torch.no_grad():
                     cpu_s, samples = timed(one_frame, 1, 3)
-            else:
-                torch.set_num_threads(ncores)
             _log("CPU legs done")
+        cpu_ref.use_c_local_attention(None)
         if fused_tail:          # the timed step ends in the fused argmax; the logits for the parity figure come from one extra untimed pass
             with torch.no_grad():
                 pred0 = outs[0:1].cpu().long()
@@ -655,14 +771,12 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         ref_gpu = ops.as_nchw(key_fn(keyframes[g0]).unsqueeze(0)).cpu()
         result["cpu_baseline"] = {"value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
                                   "host_cores": host_cores, "cpu_model": cpu_model(),
-                                  "sample": f"1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same {H}x{W} clip with "
-                                            f"the PyTorch-CPU oracle, keyframe feature precomputed outside the sample; {reps[0]} warm-up + {reps[1]} "
-                                            "timed runs at 16 threads, median; repeated at 32 and 64 threads (1 + 2 runs each; at os.cpu_count() "
-                                            "threads the strip-wise oracle does not finish a frame in a minute): `cores` / `seconds` = the fastest "
-                                            "thread count, re-timed with 1 + 3 runs.  Thread scaling is limited by the PORT, not by the host: the oracle "
-                                            "evaluates the 7x7 local attention in 16-row strips (oracle/cpu_ref.py _ROWS, which bounds its unfold buffer), "
-                                            "so beyond ~16 threads the strips' small torch ops oversubscribe -- this number is a property of the port's "
-                                            "tiling (the reference has no CPU implementation of localAttention at all)",
+                                  "sample": f"1 non-keyframe (downscale + LR backbone + MV resize + warp + CReFF + head) of the same {H}x{W} clip with the "
+                                            f"oracle (PyTorch-CPU restatement; its local attention on oracle/local_attn_ref.c's OpenMP row loops), keyframe feature "
+                                            f"precomputed outside the sample; {reps[0]} warm-up + {reps[1]} timed runs at os.cpu_count() = {host_cores} threads, median "
+                                            "(`at_all_host_cores`); repeated at 16 / 32 / 64 / 128 threads (1 + 2 runs each): `cores` / `seconds` / `value` = the "
+                                            "fastest thread count, re-timed with 1 + 3 runs (torch's CPU convs do not scale monotonically on a many-core host)",
+                                  "at_all_host_cores": {"cores": ncores, "seconds": sweep.get(ncores), "value": 1.0 / sweep[ncores] if sweep.get(ncores) else None},
                                   "seconds": cpu_s, "seconds_all": samples,
                                   "thread_sweep_seconds": {str(k): v for k, v in sorted(sweep.items())}}
         if not full:

@@ -493,6 +493,17 @@ int arseg_argmax_confusion_fwd(const float *logits, const int64_t *label, int32_
                                int n_cls, int h, int w, int H, int W, int ignore_label, int align_corners, arseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Measurement aids (no reference counterpart; BASELINE.md section 3: roofline fractions are reported against the datasheet peaks AND
+ * against on-box micro-benchmarks).  bench.py times each with HIP events and prints `peaks_measured`.
+ *   arseg_peak_stream_copy: dst[0 .. n_bytes) = src[0 .. n_bytes) with 16-byte accesses (n_bytes % 16 == 0, both 16-byte aligned):
+ *                           2 x n_bytes of HBM traffic per launch.
+ *   arseg_peak_mfma_f16:    a full-chip launch whose every wave issues iters x 8 independent v_mfma_f32_32x32x16_f16 and touches no
+ *                           memory (scratch: >= 4 bytes, never written in practice); *flops_out (may be NULL) = FLOPs issued per launch.
+ * ------------------------------------------------------------------------------------------- */
+int arseg_peak_stream_copy(const void *src, void *dst, size_t n_bytes, arseg_stream_t stream);
+int arseg_peak_mfma_f16(float *scratch, int iters, double *flops_out, arseg_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The symbol names SURVEY.md section 8(b) lists for this boundary, as aliases of the entry points above (identical arguments):
  *   arseg_creff_fused_fwd     = arseg_creff_warp_fwd      (warp + CReFF + final 1x1 in one launch)
  *   arseg_conv2d_bn_act_fwd   = arseg_conv2d_fwd          arseg_pack_weights      = arseg_pack_conv_weight_host

@@ -24,6 +24,10 @@ def _lib():
     for name in ("oracle_local_similar", "oracle_local_weighting"):
         getattr(lib, name).argtypes = [fp, fp, fp] + [ctypes.c_int] * 6
         getattr(lib, name).restype = None
+    for name in ("oracle_local_similar_mt", "oracle_local_weighting_mt"):
+        getattr(lib, name).argtypes = [fp, fp, fp] + [ctypes.c_int] * 7
+        getattr(lib, name).restype = None
+    lib.oracle_max_threads.restype = ctypes.c_int
     return lib
 
 
@@ -44,4 +48,21 @@ def local_weighting(v: np.ndarray, w: np.ndarray, kH: int, kW: int) -> np.ndarra
     N, C, H, W = v.shape
     o = np.empty_like(v)
     _lib().oracle_local_weighting(_p(v), _p(w), _p(o), N, C, H, W, kH, kW)
+    return o
+
+
+def local_similar_mt(q: np.ndarray, k: np.ndarray, kH: int, kW: int, nthreads: int = 0) -> np.ndarray:
+    """oracle_local_similar_mt: the same function, image rows in parallel over `nthreads` OpenMP threads (0: the runtime's default)."""
+    q = np.ascontiguousarray(q, np.float32); k = np.ascontiguousarray(k, np.float32)
+    N, C, H, W = q.shape
+    s = np.empty((N, H, W, kH * kW), np.float32)
+    _lib().oracle_local_similar_mt(_p(q), _p(k), _p(s), N, C, H, W, kH, kW, nthreads)
+    return s
+
+
+def local_weighting_mt(v: np.ndarray, w: np.ndarray, kH: int, kW: int, nthreads: int = 0) -> np.ndarray:
+    v = np.ascontiguousarray(v, np.float32); w = np.ascontiguousarray(w, np.float32)
+    N, C, H, W = v.shape
+    o = np.empty_like(v)
+    _lib().oracle_local_weighting_mt(_p(v), _p(w), _p(o), N, C, H, W, kH, kW, nthreads)
     return o

@@ -106,11 +106,26 @@ def downscale(imgs: torch.Tensor, scale: float) -> torch.Tensor:
 _ROWS = 16   # row strip: keeps the working set of one strip in cache (a whole 64x512x1024 plane set is 134 MB)
 
 
+_C_THREADS = None      # None: the torch strip loops below; an int n >= 0: oracle/local_attn_ref.c's OpenMP variants on n threads (0 = all)
+
+
+def use_c_local_attention(nthreads=0):
+    """Route local_similar / local_weighting through the plain-C restatement's multi-threaded variants (oracle_local_*_mt, bit-equal to its
+    scalar functions): the torch strip loops stop scaling near 16 threads, the C row loops use every host core -- what bench.py's
+    cpu_baseline leg times at os.cpu_count() threads.  ``None`` switches back.  Returns the previous setting."""
+    global _C_THREADS
+    prev, _C_THREADS = _C_THREADS, nthreads
+    return prev
+
+
 def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
     """S[n,y,x,dy*kW+dx] = sum_c q[n,c,y,x] * k[n,c,y+dy-kH//2,x+dx-kW//2]; taps outside the
     image contribute 0 (zero padding of the unfold, attention.py:56-58).  No 1/sqrt(C) scale.
     Row-tiled: a naive F.unfold materialises C*kH*kW*H*W floats (6.6 GB at 64x512x1024)."""
     N, C, H, W = q.shape
+    if _C_THREADS is not None:
+        from . import c_ref
+        return torch.from_numpy(c_ref.local_similar_mt(q.detach().numpy(), k.detach().numpy(), kH, kW, _C_THREADS))
     kp = F.pad(k, (kW // 2, kW // 2, kH // 2, kH // 2))
     out = q.new_empty(N, H, W, kH * kW)
     for y0 in range(0, H, _ROWS):
@@ -125,6 +140,9 @@ def local_similar(q: torch.Tensor, k: torch.Tensor, kH: int, kW: int) -> torch.T
 def local_weighting(v: torch.Tensor, w: torch.Tensor, kH: int, kW: int) -> torch.Tensor:
     """O[n,c,y,x] = sum_i v[n,c,y+dy_i,x+dx_i] * w[n,y,x,i], zero padded (attention.py:75-85)."""
     N, C, H, W = v.shape
+    if _C_THREADS is not None:
+        from . import c_ref
+        return torch.from_numpy(c_ref.local_weighting_mt(v.detach().numpy(), w.detach().numpy(), kH, kW, _C_THREADS))
     vp = F.pad(v, (kW // 2, kW // 2, kH // 2, kH // 2))
     out = torch.empty_like(v)
     for y0 in range(0, H, _ROWS):

@@ -64,3 +64,100 @@ void oracle_local_weighting(const float *v, const float *w, float *o,
                 }
         }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * The same two functions for the timed CPU leg of bench.py (the CPU path runs on every host core): rows of the
+ * image in parallel (OpenMP), the inner loops over x so that they vectorise.  Same products, same accumulation order per output
+ * (channels ascending for `similar`, taps in row-major order for `weighting`), contraction off (Makefile: -ffp-contract=off): the
+ * results equal the scalar functions above bit for bit (tests/test_oracle_golden.py::test_c_oracle_mt_equals_scalar).
+ * ------------------------------------------------------------------------------------------- */
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+void oracle_local_similar_mt(const float *q, const float *k, float *s,
+                             int N, int C, int H, int W, int kH, int kW, int nthreads)
+{
+    const int rH = kH / 2, rW = kW / 2, T = kH * kW;
+    const size_t plane = (size_t)H * W;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        float *acc = (float *)malloc((size_t)T * W * sizeof(float));      /* one row of scores, tap-major */
+#pragma omp for collapse(2) schedule(static)
+        for (int n = 0; n < N; ++n)
+            for (int y = 0; y < H; ++y) {
+                memset(acc, 0, (size_t)T * W * sizeof(float));
+                for (int c = 0; c < C; ++c) {
+                    const float *qr = q + ((size_t)n * C + c) * plane + (size_t)y * W;
+                    for (int dy = 0; dy < kH; ++dy) {
+                        const int yy = y + dy - rH;
+                        if (yy < 0 || yy >= H) continue;
+                        const float *kr = k + ((size_t)n * C + c) * plane + (size_t)yy * W;
+                        for (int dx = 0; dx < kW; ++dx) {
+                            float *a = acc + (size_t)(dy * kW + dx) * W;
+                            const int off = dx - rW, x0 = off < 0 ? -off : 0, x1 = off > 0 ? W - off : W;
+                            for (int x = x0; x < x1; ++x) a[x] += qr[x] * kr[x + off];
+                        }
+                    }
+                }
+                float *so = s + (((size_t)n * H + y) * W) * T;
+                for (int t = 0; t < T; ++t)
+                    for (int x = 0; x < W; ++x) so[(size_t)x * T + t] = acc[(size_t)t * W + x];
+            }
+        free(acc);
+    }
+}
+
+void oracle_local_weighting_mt(const float *v, const float *w, float *o,
+                               int N, int C, int H, int W, int kH, int kW, int nthreads)
+{
+    const int rH = kH / 2, rW = kW / 2, T = kH * kW;
+    const size_t plane = (size_t)H * W;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel
+    {
+        float *wt = (float *)malloc((size_t)T * W * sizeof(float));       /* one row of weights, tap-major */
+#pragma omp for collapse(2) schedule(static)
+        for (int n = 0; n < N; ++n)
+            for (int y = 0; y < H; ++y) {
+                const float *wr = w + (((size_t)n * H + y) * W) * T;
+                for (int t = 0; t < T; ++t)
+                    for (int x = 0; x < W; ++x) wt[(size_t)t * W + x] = wr[(size_t)x * T + t];
+                for (int c = 0; c < C; ++c) {
+                    float *orow = o + ((size_t)n * C + c) * plane + (size_t)y * W;
+                    for (int x = 0; x < W; ++x) orow[x] = 0.0f;
+                    for (int dy = 0; dy < kH; ++dy) {
+                        const int yy = y + dy - rH;
+                        if (yy < 0 || yy >= H) continue;
+                        const float *vr = v + ((size_t)n * C + c) * plane + (size_t)yy * W;
+                        for (int dx = 0; dx < kW; ++dx) {
+                            const float *a = wt + (size_t)(dy * kW + dx) * W;
+                            const int off = dx - rW, x0 = off < 0 ? -off : 0, x1 = off > 0 ? W - off : W;
+                            for (int x = x0; x < x1; ++x) orow[x] += vr[x + off] * a[x];
+                        }
+                    }
+                }
+            }
+        free(wt);
+    }
+}

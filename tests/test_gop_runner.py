@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from arseg_amd.gop import GopRunner, frame_plan, keyframe_owner
+from arseg_amd.gop import GopRunner, frame_plan, keyframe_owner, neighbor_plan
 
 
 def test_frame_plan_covers_every_frame_once():
@@ -18,6 +18,24 @@ def test_frame_plan_covers_every_frame_once():
         assert all(len(r) == 11 for r in plan)                      # balanced: every rank gets gop-1 frames
         assert {g for g, _ in flat} == set(range(world)) and {d for _, d in flat} == set(range(1, 12))
     assert keyframe_owner(5, 4) == 1
+
+
+def test_neighbor_plan_spans_two_gops_per_rank():
+    """The contiguous-run deal: every frame once, gop-1 frames per owned GOP per rank, and a rank's frames come from the GOPs
+    it owns plus the GOPs of rank+1 only -- one foreign keyframe feature per owned GOP instead of world-1."""
+    for world in (1, 2, 4, 8):
+        for n_gops in (world, 2 * world):
+            plan = neighbor_plan(n_gops, 12, world)
+            flat = [f for r in plan for f in r]
+            assert len(flat) == len(set(flat)) == n_gops * 11
+            assert all(len(r) == 11 * n_gops // world for r in plan)
+            for r, fr in enumerate(plan):
+                owners = {keyframe_owner(g, world) for g, _ in fr}
+                assert owners <= {r, (r + 1) % world}
+                for g in {g for g, _ in fr}:                     # a GOP is cut once: its first half to the previous owner, the rest to its owner
+                    ds = sorted(d for gg, d in fr if gg == g)
+                    assert ds == (list(range(6, 12)) if keyframe_owner(g, world) == r and world > 1 else
+                                  list(range(1, 6)) if world > 1 else list(range(1, 12)))
 
 
 def _key_fn(k):
@@ -50,7 +68,10 @@ def _worker(rank, world, port, q, mode="batched"):
     n_gops = 1 if mode in ("single", "loopback-broadcast") else world
     keys, frames, mvs = _data(n_gops)
     loop = {"loopback": "all_gather", "loopback-overlapped": "all_gather", "loopback-broadcast": "broadcast"}.get(mode, False)
-    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops, local=mode.startswith("local"), loopback=loop)
+    runner = GopRunner(_key_fn, _nonkey_fn, n_gops=n_gops, local=mode.startswith("local"), loopback=loop,
+                       deal="neighbor" if mode.startswith("neighbor") else "round_robin")
+    if mode.startswith("neighbor") and world > 1:
+        assert runner.neighbor and {keyframe_owner(g, world) for g, _ in runner.plan} == {rank, (rank + 1) % world}
     if loop:
         assert world == 1 and runner.loopback and runner.single_gop == (loop == "broadcast")
         calls = []
@@ -62,7 +83,7 @@ def _worker(rank, world, port, q, mode="batched"):
     like = torch.empty(3, 8, 8)
     if mode.startswith("local"):
         assert runner.plan == [(rank, d) for d in range(1, 12)]       # whole GOP `rank`, nothing from the other ranks' GOPs
-    if mode in ("overlapped", "local-overlapped", "loopback-overlapped"):        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
+    if mode in ("overlapped", "local-overlapped", "loopback-overlapped", "neighbor-overlapped"):        # HR forward -> exchange || phase 1 -> phase 2, the rank's frames as one batch
         fs = torch.stack([frames[f] for f in runner.plan])
         ms = torch.stack([mvs[f] for f in runner.plan])
         res = runner.run_overlapped({g: keys[g] for g in runner.my_gops}, fs, ms, _phase1, _phase2)
@@ -83,13 +104,15 @@ import pytest
 
 @pytest.mark.parametrize("world,mode", [(2, "batched"), (2, "overlapped"), (2, "single"), (4, "batched"), (4, "single"),
                                         (8, "overlapped"), (8, "single"), (2, "local"), (4, "local-overlapped"),
-                                        (1, "loopback"), (1, "loopback-overlapped"), (1, "loopback-broadcast")])
+                                        (1, "loopback"), (1, "loopback-overlapped"), (1, "loopback-broadcast"),
+                                        (2, "neighbor"), (4, "neighbor-overlapped"), (8, "neighbor")])
 def test_multi_rank_gloo_matches_single_process(world, mode):
     """world 2 / 4 / 8 over gloo == the single-process run, bit for bit: the batched plan (all-gather), the overlapped schedule (exchange
     concurrent with phase 1) and the single-GOP plan (owner broadcasts ref_p, 11 frames dealt over the ranks -- at world 8 three ranks
     get two frames and five get one: the literal north-star configuration, BASELINE configs[3] is the batched plan at world 8); and the
     zero-communication comparison plan of SURVEY 8e ("local": rank g keeps GOP g whole, no collective on the data path).  world 1
-    "loopback": a one-rank group that still issues its collective (how the exchange code meets RCCL on a 1-GPU box)."""
+    "loopback": a one-rank group that still issues its collective (how the exchange code meets RCCL on a 1-GPU box).  "neighbor": the
+    contiguous-run deal of round 6 -- one grouped send / receive of the keyframe feature between ring neighbours instead of the all-gather."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]

@@ -465,6 +465,40 @@ def test_batched_fast_path_equals_per_frame(dev, manifest, kind):
             assert maxdiff(p_b[i:i + 1], p_i) <= 2e-4
 
 
+@pytest.mark.parametrize("kind", ["psp", "bise", "semseg"])
+def test_fast_paths_without_aux_outputs(dev, manifest, kind):
+    """The build's fast paths skip the training-only auxiliary outputs the evaluator discards (evaluation.py:173-174 takes ``[-1]`` of the
+    keyframe forward, :190-191 ``[-1]`` of forward_phase1): ``forward_keyframe`` / ``phase1_nhwc4(aux=False)`` must return exactly what
+    ``forward`` / ``forward_phase1`` return at those positions (same launches, same plans), and ``forward`` itself still returns every output
+    of the reference; ``ops.config.aux_outputs`` switches the fast paths back."""
+    from arseg_amd import evaluation as ev
+    from arseg_amd import ops, synth
+
+    mk = {"psp": _psp, "bise": _bise}.get(kind)
+    hr = mk(manifest, dev, False) if mk else _semseg(manifest, dev, 4)
+    lr = mk(manifest, dev, True) if mk else _semseg(manifest, dev, 5)
+    H, W = (64, 96) if kind == "psp" else (128, 256)
+    clip = synth.make_clip(7, H, W, gop=3)
+    frames = torch.from_numpy(clip["frames"]).to(dev)
+    mvs = torch.from_numpy(clip["mv"]).to(dev)
+    with torch.no_grad():
+        full = hr(frames[0:1])
+        out_k, feat_k = hr.forward_keyframe(frames[0:1])
+        assert len(full) >= 3                                   # the reference's tuple, aux outputs included
+        assert torch.equal(out_k, full[0]) and torch.equal(ops.as_nchw(feat_k), full[-1])
+        x4 = ops.frame_ingest(frames[1:2], H // 2, W // 2, lr.storage_dtype)
+        with_aux, without = lr.phase1_nhwc4(x4), lr.phase1_nhwc4(x4, aux=False)
+        assert torch.equal(with_aux[-1], without[-1])
+        ref_p = feat_k[0]
+        a, pa = ev.alter_res_batch_fast(lr, [ref_p] * 2, frames[1:3], mvs[1:3], 0.5)
+        prev = ops.configure(aux_outputs=True)
+        try:
+            b, pb = ev.alter_res_batch_fast(lr, [ref_p] * 2, frames[1:3], mvs[1:3], 0.5)
+        finally:
+            ops.configure(**prev)
+        assert torch.equal(a, b) and torch.equal(pa, pb)
+
+
 def test_gop_runner_single_gpu(dev, manifest):
     """GopRunner without a process group (world 1): keyframe -> exchange (no-op) -> batched non-keyframes."""
     from arseg_amd import evaluation as ev

@@ -67,6 +67,29 @@ def test_g3_local_attention_pair(golden):
     assert maxdiff(c_ref.local_similar(g["q"], g["v"], kH, kW), g["similar_shim"]) <= TOL
 
 
+def test_c_oracle_mt_equals_scalar(golden):
+    """oracle/local_attn_ref.c's OpenMP variants (what bench.py's CPU leg times on every host core) == its scalar functions bit for bit, on the
+    reference-generated pair fixture and on a ragged random case; cpu_ref routed through them reproduces G3."""
+    g = golden("g3_pair")
+    kH, kW = int(g["kH"]), int(g["kW"])
+    assert np.array_equal(c_ref.local_similar_mt(g["q"], g["v"], kH, kW, 3), c_ref.local_similar(g["q"], g["v"], kH, kW))
+    assert np.array_equal(c_ref.local_weighting_mt(g["v"], g["w"], kH, kW, 3), c_ref.local_weighting(g["v"], g["w"], kH, kW))
+    rng = np.random.default_rng(5)
+    q, k = rng.standard_normal((2, 5, 9, 13), dtype=np.float32), rng.standard_normal((2, 5, 9, 13), dtype=np.float32)
+    w = rng.standard_normal((2, 9, 13, 15), dtype=np.float32)
+    assert np.array_equal(c_ref.local_similar_mt(q, k, 3, 5, 4), c_ref.local_similar(q, k, 3, 5))
+    assert np.array_equal(c_ref.local_weighting_mt(q, w, 3, 5, 4), c_ref.local_weighting(q, w, 3, 5))
+    g = golden("g3_attn_c1_s0")
+    sd = {k_[2:]: t(g[k_]) for k_ in g.files if k_.startswith("w.")}
+    kk = int(g["k"])
+    prev = cpu_ref.use_c_local_attention(2)
+    try:
+        out = cpu_ref.my_attention(sd, "", t(g["hr"]), t(g["lr"]), kk, kk)
+    finally:
+        cpu_ref.use_c_local_attention(prev)
+    assert maxdiff(out, g["out"]) <= TOL
+
+
 def test_g4_pspnet(golden, manifest):
     g = golden("g4_pspnet")
     sd = sd_from_manifest(manifest, "PSPNet", 0)
