@@ -91,12 +91,9 @@ void oracle_local_similar_mt(const float *q, const float *k, float *s,
 {
     const int rH = kH / 2, rW = kW / 2, T = kH * kW;
     const size_t plane = (size_t)H * W;
-#ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
-#else
-    (void)nthreads;
-#endif
-#pragma omp parallel
+    /* (a num_threads clause, not omp_set_num_threads: the OpenMP runtime is shared with torch, whose thread count must not change) */
+    const int nt = nthreads > 0 ? nthreads : oracle_max_threads();
+#pragma omp parallel num_threads(nt)
     {
         float *acc = (float *)malloc((size_t)T * W * sizeof(float));      /* one row of scores, tap-major */
 #pragma omp for collapse(2) schedule(static)
@@ -129,12 +126,9 @@ void oracle_local_weighting_mt(const float *v, const float *w, float *o,
 {
     const int rH = kH / 2, rW = kW / 2, T = kH * kW;
     const size_t plane = (size_t)H * W;
-#ifdef _OPENMP
-    if (nthreads > 0) omp_set_num_threads(nthreads);
-#else
-    (void)nthreads;
-#endif
-#pragma omp parallel
+    /* (a num_threads clause, not omp_set_num_threads: the OpenMP runtime is shared with torch, whose thread count must not change) */
+    const int nt = nthreads > 0 ? nthreads : oracle_max_threads();
+#pragma omp parallel num_threads(nt)
     {
         float *wt = (float *)malloc((size_t)T * W * sizeof(float));       /* one row of weights, tap-major */
 #pragma omp for collapse(2) schedule(static)
