@@ -12,7 +12,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ARSEG_HIP_LIB", os.path.join(_HERE, "lib", "libarseg_hip.so"))   # env override: kernel experiments
 
-ABI_VERSION = 4          # ARSEG_ABI_VERSION of include/arseg_hip.h
+ABI_VERSION = 5          # ARSEG_ABI_VERSION of include/arseg_hip.h
 ARSEG_OK, ARSEG_EINVAL, ARSEG_EUNSUPPORTED, ARSEG_EWORKSPACE = 0, -1, -2, -3
 ACT_NONE, ACT_RELU, ACT_PRELU, ACT_SIGMOID = 0, 1, 2, 3
 NCHW, NHWC, C8 = 0, 1, 2
@@ -20,8 +20,6 @@ FLOW_F32, FLOW_F64 = 0, 1
 NEAREST, BILINEAR = 0, 1
 REDUCE_MEAN, REDUCE_MAX = 0, 1
 MATH_F32, MATH_F16X3, MATH_F16 = 0, 1, 2
-ROWS_X3, ROWS_F16, ROWS_BF16 = 0, 1, 2          # enum arseg_rows_fmt
-ROWS_OUT_NHWC, ROWS_OUT_PADDED = 0, 1          # enum arseg_rows_out
 DT_F32, DT_F16, DT_BF16 = 0, 1, 2
 
 
@@ -65,9 +63,7 @@ PROTOTYPES = {
     "arseg_creff_warp_select": (c_int, [c_int] * 12),
     "arseg_peak_stream_copy": (c_int, [_P, _P, c_size_t, _STREAM]),
     "arseg_peak_mfma_f16": (c_int, [_P, c_int, POINTER(c_double), _STREAM]),
-    "arseg_conv3x3_rows_fwd": (c_int, [_P, _P, _P] + [c_int] * 9 + [_P, _P, _P, c_int, c_int, c_int, c_float, c_int, _P, c_float, _STREAM]),
     "arseg_gemm_rows16_fwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_float, c_int, _STREAM]),
-    "arseg_pad_rows_fwd": (c_int, [_P, c_int64, _P] + [c_int] * 6 + [_P, c_float, _STREAM]),
     "arseg_split_rows_fwd": (c_int, [_P, c_int64, _P, c_int64, c_int, c_float, _P, c_float, _STREAM]),
     "arseg_gemm_x3_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, _P, c_int, c_int, c_float, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_gemm_x3_cat_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int64, _P, _P,

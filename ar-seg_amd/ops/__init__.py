@@ -21,8 +21,8 @@ from ._base import _DT16, _need_gpu, _need_gpu16, _nhwc_ld, _ptr, _range_word, _
 from ._config import Config, config, configure, set_conv_math
 from ._plans import _conv_plans, _time
 from ._profile import profile
-from .conv import (PaddedRows, SplitRows, _conv1x1_x3, _conv2d16, _conv_up2_taps, _conv_wino, conv2d, conv3x3_rows, gemm_rows16, gemm_x3_enabled, igemm3_enabled,
-                   pad_rows, psp_bottleneck_x3, psp_x3_foldable, rows_eligible, split_rows)
+from .conv import (SplitRows, _conv1x1_x3, _conv2d16, _conv_up2_taps, _conv_wino, conv2d, gemm_rows16, gemm_x3_enabled, igemm3_enabled,
+                   psp_bottleneck_x3, psp_x3_foldable, split_rows)
 from .creff import creff, creff_warp, creff_warp_kernel, flow_resize, mv_resize, warp, warp_mvq
 from .layers import (adaptive_avgpool, argmax_confusion, as_nchw, cast, frame_ingest, frame_to_nhwc4, frame_u8_to_nhwc4, from_c8, global_reduce, head,
                      is_nhwc_view, local_similar, local_weighting, maxpool3x3s2, merge_motion, psp_pool_matrix, psp_prior_sum, resize_nchw, resize_nhwc,

@@ -35,146 +35,14 @@ class SplitRows:
         return (hl[..., 0, :] + hl[..., 1, :]).reshape(n, h, w, c)
 
 
-class PaddedRows:
-    """An NHWC activation stored as a ZERO-BORDERED image ``t`` [N, H + 2 pad, W + 2 pad, C] in a row format of the LDS-DMA kernel: split rows
-    (``t`` float32-typed, the same 4 bytes per value) on the fp32 path, plain fp16 / bf16 values on the 16-bit storage path.  The activation
-    operand of ``conv3x3_rows`` (the 3x3 stride-1 conv as an implicit GEMM: GEMM row = padded pixel, tap = row offset, padding = this border);
-    written by ``pad_rows`` or by a ``conv3x3_rows(..., out_padded=True)`` whose consumer is again such a conv of the same dilation."""
-    __slots__ = ("t", "pad")
-
-    def __init__(self, t, pad):
-        self.t, self.pad = t, int(pad)
-
-    device = property(lambda self: self.t.device)
-    fmt = property(lambda self: _lib.ROWS_X3 if self.t.dtype == torch.float32 else (_lib.ROWS_BF16 if self.t.dtype == torch.bfloat16 else _lib.ROWS_F16))
-
-    @property
-    def shape(self):          # the logical (unpadded) NHWC shape
-        n, hp, wp, c = self.t.shape
-        return (n, hp - 2 * self.pad, wp - 2 * self.pad, c)
-
-    def interior(self):
-        """The unpadded NHWC tensor (a copy; torch ops on the device -- tests and fallback paths only)."""
-        p = self.pad
-        t = SplitRows(self.t).float() if self.t.dtype == torch.float32 else self.t
-        return t[:, p:t.shape[1] - p, p:t.shape[2] - p, :].contiguous()
-
-
 def igemm3_enabled(x=None) -> bool:
-    """May 3x3 stride-1 convs run as an implicit GEMM of the LDS-DMA kernel?  fp32 path: as gemm_x3_enabled() (f16x3 arithmetic, no
-    host-synchronising range guard); 16-bit path: always (ops.config.conv_igemm3 switches both)."""
-    if not sw.IGEMM3:
-        return False
-    if x is not None and (is16(x) or (isinstance(x, PaddedRows) and x.fmt != _lib.ROWS_X3)):
-        return True
-    return gemm_x3_enabled()
-
-
-def rows_eligible(pc, cin: int, fmt: int) -> bool:
-    """The shapes arseg_conv3x3_rows_fwd takes: 3x3, stride 1, padding == dilation, whole 128-byte channel groups."""
-    gran = 32 if fmt == _lib.ROWS_X3 else 64
-    return pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == pc.dil and 1 <= pc.dil <= 8 and cin % gran == 0 and pc.cout % 4 == 0
-
-
-def pad_rows(x: torch.Tensor, pad: int, record: bool = True) -> PaddedRows:
-    """NHWC tensor (fp32, or fp16 / bf16 on the 16-bit path; may be a channel slice) -> PaddedRows with a zero border of ``pad`` pixels: one
-    memory-bound pass (arseg_pad_rows_fwd); for split rows it carries the operand range watch of the conv that will read it."""
-    n, h, w, c = x.shape
-    if is16(x):
-        _need_gpu16(x)
-        t = torch.empty((n, h + 2 * pad, w + 2 * pad, c), dtype=x.dtype, device=x.device)
-        fmt, rw = (_lib.ROWS_BF16 if x.dtype == torch.bfloat16 else _lib.ROWS_F16), None
-    else:
-        _need_gpu(x)
-        t = torch.empty((n, h + 2 * pad, w + 2 * pad, c), dtype=torch.float32, device=x.device)
-        fmt, rw = _lib.ROWS_X3, (_range_word(x.device) if sw.RANGE_MODE == "device" else None)
-    args = (_ptr(x), _nhwc_ld(x), _ptr(t), fmt, n, h, w, c, pad, _ptr(rw), 65504.0, _stream())
-    if record:
-        launch("pad_rows", _lib.load().arseg_pad_rows_fwd, *args)
-    else:
-        check(_lib.load().arseg_pad_rows_fwd(*args), "pad_rows")
-    return PaddedRows(t, pad)
+    """May the 1x1 convs of the 16-bit storage path run as a plain GEMM of the LDS-DMA kernel (gemm_rows16)?  ``ops.config.conv_igemm3``.
+    (The knob's name is historical: rounds 5's implicit-3x3 route on zero-bordered rows -- arseg_conv3x3_rows_fwd / arseg_pad_rows_fwd -- measured
+    parity with the patch-resident kernels on every bench shape, was never selected, and was removed from the tuner and the ABI in round 6.)"""
+    return bool(sw.IGEMM3)
 
 
 _ROWS_CFGS = (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11)
-
-
-def conv3x3_rows(x: PaddedRows, pc, residual=None, out_padded: bool = False, out: Optional[torch.Tensor] = None, cfg: Optional[int] = None,
-                 record: bool = True):
-    """3x3 stride-1 conv (+ folded BN / bias, residual, activation of ``pc``) on a PaddedRows input as an implicit GEMM of the LDS-DMA kernel
-    (arseg_conv3x3_rows_fwd).  residual: an NHWC tensor of the output's element type, or a PaddedRows of the input's format and geometry (the
-    block input).  out_padded: the result is a PaddedRows of the same geometry (the next conv reads it as it is); otherwise an NHWC tensor (fp32 on
-    the fp32 path, the storage dtype on the 16-bit path; ``out`` optionally receives it -- may be a channel slice).  cfg None: the tile shape is
-    timed on first use per shape."""
-    lib = _lib.load()
-    n, h, w, cin = x.shape
-    fmt, dev, cout = x.fmt, x.device, pc.cout
-    if x.pad != pc.dil or not rows_eligible(pc, cin, fmt):
-        raise _lib.ArsegError("conv3x3_rows: a 3x3 stride-1 conv with padding == dilation == the input's border is required")
-    if fmt == _lib.ROWS_X3:
-        if cin != pc.cin_pad:
-            raise _lib.ArsegError(f"conv expects {pc.cin_pad} input channels, got {cin}")
-        w_dev, scale_dev, odt = pc.w_h3, pc.scale_h3, torch.float32
-    else:
-        w_dev, cin16 = pc.weights16(x.t.dtype)
-        if cin != cin16:
-            raise _lib.ArsegError(f"conv (16-bit) expects {cin16} input channels, got {cin}")
-        scale_dev, odt = pc.scale, x.t.dtype
-    if out_padded and (cout % (32 if fmt == _lib.ROWS_X3 else 8)):
-        out_padded = False
-    res_mode, res_ld = _lib.ROWS_OUT_NHWC, 0
-    if isinstance(residual, PaddedRows):
-        if residual.pad != x.pad or tuple(residual.t.shape) != (n, h + 2 * x.pad, w + 2 * x.pad, cout) or residual.t.dtype != x.t.dtype:
-            raise _lib.ArsegError("conv3x3_rows: a padded residual must have the input's format and geometry and Cout channels")
-        res_mode, res_ld, res_t = _lib.ROWS_OUT_PADDED, cout, residual.t
-    elif residual is not None:
-        if tuple(residual.shape) != (n, h, w, cout) or residual.dtype != odt:
-            raise _lib.ArsegError("residual shape / dtype mismatch")
-        res_ld, res_t = _nhwc_ld(residual), residual
-    else:
-        res_t = None
-    if out_padded:
-        o = torch.empty((n, h + 2 * x.pad, w + 2 * x.pad, cout), dtype=x.t.dtype, device=dev)
-        out_ld = cout
-    else:
-        if out is None:
-            cl = cout if fmt == _lib.ROWS_X3 else (cout + 7) // 8 * 8
-            out = torch.empty((n, h, w, cl), dtype=odt, device=dev)[..., :cout]
-        elif tuple(out.shape) != (n, h, w, cout) or out.dtype != odt:
-            raise _lib.ArsegError(f"conv out has shape {tuple(out.shape)} / {out.dtype}, expected {(n, h, w, cout)} / {odt}")
-        o, out_ld = out, _nhwc_ld(out)
-    rw = _range_word(dev) if (out_padded and fmt == _lib.ROWS_X3 and sw.RANGE_MODE == "device") else None
-    flops = 2 * n * h * w * cout * 9 * pc.cin
-
-    def run(c, rec):
-        args = (_ptr(x.t), _ptr(w_dev), _ptr(o), fmt, n, h, w, cin, cout, pc.dil, _lib.ROWS_OUT_PADDED if out_padded else _lib.ROWS_OUT_NHWC, out_ld,
-                _ptr(scale_dev), _ptr(pc.bias), _ptr(res_t), res_mode, res_ld, pc.act, pc.slope, c, _ptr(rw), 65504.0, _stream())
-        if rec:
-            launch("conv2d", lib.arseg_conv3x3_rows_fwd, *args, flops=flops)
-        else:
-            check(lib.arseg_conv3x3_rows_fwd(*args), "conv3x3_rows")
-
-    if cfg is None:
-        key = ("rows3", dev.index, fmt, n, h, w, cin, cout, pc.dil, bool(out_padded), res_mode if res_t is not None else -1)
-        cfg = _conv_plans.get(key)
-        if cfg is None:
-            if not sw.AUTOTUNE or torch.cuda.is_current_stream_capturing():
-                cfg = 7 if cout <= 64 else (10 if n * h * w < 65536 else 3)          # un-timed and not cached
-            else:
-                best_t = float("inf")
-                for c in _ROWS_CFGS:
-                    try:
-                        tm = _time(lambda: run(c, False))
-                    except _lib.ArsegError:
-                        continue
-                    if tm < best_t:
-                        cfg, best_t = c, tm
-                if cfg is None:
-                    raise _lib.ArsegError(f"conv3x3_rows: no tile configuration accepts N={n} {h}x{w} {cin}->{cout}")
-                _conv_plans[key] = cfg
-    with tagged(lambda: (n, h, w, pc.cin, cout, 3, 1, pc.dil, False, f"rows3({cfg})", flops)):
-        run(cfg, record)
-    return PaddedRows(o, x.pad) if out_padded else o
 
 
 def gemm_rows16(x: torch.Tensor, pc, residual=None, out: Optional[torch.Tensor] = None, cfg: Optional[int] = None, record: bool = True):
@@ -405,10 +273,6 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
     def launch_x3(record=True):
         _conv1x1_x3(x, pc, residual, out, False, None, record)
 
-    def launch_rows(record=True):
-        # pad pass + implicit 3x3 GEMM of the LDS-DMA kernel (conv3x3_rows); a conv -> conv chain that stays in padded rows skips the pass
-        conv3x3_rows(pad_rows(x, pc.dil, record=record), pc, residual, out=out, record=record)
-
     def find_native():
         """Plan selection inside the library (arseg_conv2d_find: every candidate timed with HIP events, no Python in the loop).  With a
         fused upsample only the patch-resident plans qualify; None = nothing launched (the Python tuner then tries the rest)."""
@@ -432,10 +296,8 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
         taps_ok = (x_low is not None and sw.UP2_TAPS and residual is None and pc.R == 3 and pc.S == 3 and pc.stride == 1 and pc.pad == 1
                    and pc.dil == 1 and pc.cout % 4 == 0)
         x3_ok = _x3_eligible(pc, Cin, residual, x_low is not None) and not wino_ok
-        rows_ok = x_low is None and igemm3_enabled() and math == _lib.MATH_F16X3 and rows_eligible(pc, Cin, _lib.ROWS_X3)
         plan = _conv_plans.get(key)
-        if ((plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or (plan == "rows" and not rows_ok)
-                or plan == "tapsf"):      # a persisted plan whose route is switched off / gone: re-tune
+        if ((plan == "wino" and not wino_ok) or (plan == "taps" and not taps_ok) or (plan == "x3" and not x3_ok) or plan in ("rows", "tapsf")):      # a persisted plan whose route is switched off / gone: re-tune
             plan = None
         if plan is None:
             plan = find_native() if sw.NATIVE_FIND else None
@@ -472,17 +334,9 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                         plan = "x3"
                 except _lib.ArsegError:
                     pass
-            if rows_ok:                                         # pad pass + implicit 3x3 GEMM on the LDS-DMA kernel against the best so far
-                try:
-                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: run_plan(*plan, record=False)))
-                    launch_rows(record=False)                   # picks its tile shape
-                    if _time(lambda: launch_rows(record=False)) < t_best:
-                        plan = "rows"
-                except _lib.ArsegError:
-                    pass
             if taps_ok:
                 try:
-                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else ((lambda: launch_rows(record=False)) if plan == "rows" else (lambda: run_plan(*plan, record=False))))
+                    t_best = _time((lambda: launch_wino(record=False)) if plan == "wino" else (lambda: run_plan(*plan, record=False)))
                     launch_taps(record=False)                   # tunes the low-resolution GEMM underneath
                     if _time(lambda: launch_taps(record=False)) < t_best:
                         plan = "taps"
@@ -496,8 +350,6 @@ def conv2d(x: torch.Tensor, pc, residual: Optional[torch.Tensor] = None, out: Op
                 launch_taps()
             elif plan == "x3":
                 launch_x3()
-            elif plan == "rows":
-                launch_rows()
             else:
                 run_plan(*plan)
     else:
@@ -570,23 +422,11 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
                         plan = "gemm16"
                 except _lib.ArsegError:
                     pass
-            if igemm3_enabled(x) and not up2 and rows_eligible(pc, Cin, _lib.ROWS_BF16):      # pad pass + implicit 3x3 GEMM on the LDS-DMA kernel
-                try:
-                    conv3x3_rows(pad_rows(x, pc.dil, record=False), pc, residual, out=out, record=False)
-                    if _time(lambda: conv3x3_rows(pad_rows(x, pc.dil, record=False), pc, residual, out=out, record=False)) < best_t:
-                        plan = "rows"
-                except _lib.ArsegError:
-                    pass
             _conv_plans[key] = plan
         #  the plan key holds the shape, not the alignment / row pitch of `out` and `residual`: a later call with a channel-slice
         # view the LDS-DMA kernel refuses (EINVAL) falls back to the library's heuristic instead of raising
-        if plan == "rows":
-            if igemm3_enabled(x) and rows_eligible(pc, Cin, _lib.ROWS_BF16):
-                try:
-                    return conv3x3_rows(pad_rows(x, pc.dil), pc, residual, out=out)
-                except _lib.ArsegError:
-                    pass
-            plan = (0, 0)                      # the route was switched off after the plan was cached: the library's heuristic
+        if plan == "rows":                     # (a plan file of round 5: the route is gone)
+            plan = (0, 0)
         if plan == "gemm16":
             if igemm3_enabled(x) and d.in_ld == Cin:
                 try:

@@ -561,7 +561,7 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         tot_flops = conv["flops"] / 3 + conv_k["flops"]
         tot_ms = conv["ms"] / 3 + conv_k["ms"]
         n_launch = conv["launches"] / 3 + conv_k["launches"]
-        aux = ("wino_input", "wino_output", "up2_tap_gather", "split_rows", "pad_rows")      # memory-bound passes that belong to a conv: Winograd transforms, tap gather, split pre-pass
+        aux = ("wino_input", "wino_output", "up2_tap_gather", "split_rows")      # memory-bound passes that belong to a conv: Winograd transforms, tap gather, split pre-pass
         wino_ms = sum(nk.get(k, {"ms": 0.0})["ms"] for k in aux) / 3 + sum(ky.get(k, {"ms": 0.0})["ms"] for k in aux)
         ref_flops = ((GOP - 1) * cfg["ref_lr_gflop"] + cfg["ref_hr_gflop"]) * 1e9
         mfma_mult, peak = {"f16x3": (3.0, PEAK_F16_MFMA_TFLOPS), "f16": (1.0, PEAK_F16_MFMA_TFLOPS), "f32": (1.0, PEAK_FP32_MFMA_TFLOPS)}[args.conv_math]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ARSEG_ABI_VERSION 4
+#define ARSEG_ABI_VERSION 5
 
 enum arseg_status {
     ARSEG_OK = 0,
@@ -301,36 +301,15 @@ int arseg_gemm_x3_cat_fwd(const void *x_split, const void *w_split, const void *
                           float prelu_slope, int out_split, int tile_cfg, void *range_flag, float range_limit, arseg_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * 3x3 stride-1 convolution (padding == dilation) + folded BN / bias + residual + activation as an IMPLICIT GEMM of the LDS-DMA kernel
- * (csrc/gemm_x3.hip) -- extractors.BasicBlock (/root/reference/model/extractors.py:35-66), bisenet.BasicBlock / ConvBNReLU
- * (/root/reference/model/bisenet.py:31-60,162-186).  No im2col, no register-staged operand:
- *   x_rows : the input as a ZERO-BORDERED NHWC image [N][H + 2 dil][W + 2 dil][Cin] in a row format (enum arseg_rows_fmt):
- *            ARSEG_ROWS_X3 = split rows (the fp32-grade format of arseg_gemm_x3_fwd, Cin % 32 == 0), ARSEG_ROWS_F16 / _BF16 = plain 16-bit values
- *            (the 16-bit storage path, Cin % 64 == 0).  arseg_pad_rows_fwd builds it from an NHWC tensor; a conv with out_mode PADDED writes it.
- *   w_rows : [Cout][9 * Cin], k = (r * 3 + s) * Cin + ci, in the same format (arseg_split_weight_f16x3_host / arseg_pack_conv_weight16_host).
- *   GEMM row m is padded pixel m; tap (r, s) reads row m + ((r - 1) * (W + 2 dil) + (s - 1)) * dil; the padding is the image's own border.
- *   out_mode ARSEG_ROWS_OUT_NHWC  : out = unpadded NHWC [N][H][W][Cout] (row stride out_ld elements): fp32 for ROWS_X3, 16-bit for the 16-bit formats;
- *            ARSEG_ROWS_OUT_PADDED: out = zero-bordered rows of the input's format and geometry [N][H + 2 dil][W + 2 dil][Cout] (out_ld == Cout;
- *            Cout % 32 == 0 for split rows): the next 3x3 conv of the same dilation reads it as it is -- border rows are written as zeros.
- *   residual (may be NULL): res_mode ARSEG_ROWS_OUT_NHWC = unpadded NHWC in the output's element type (row stride res_ld), ARSEG_ROWS_OUT_PADDED =
- *            zero-bordered rows in the input's format and geometry (res_ld == Cout), e.g. the block input that conv1 of the block also read.
- *   out = act(scale[co] * sum + bias[co] + residual); scale / bias fp32 (NULL: 1 / 0).  range_flag / range_limit: as arseg_conv_desc, armed for
- *   split-row outputs.  tile_cfg 0-11 (0-6 as arseg_gemm_x3_fwd, 7-11 narrow tiles for Cout = 64 / 128); none is chosen for the caller.
- * Cost of the border: (H + 2 dil)(W + 2 dil) / (H W) of the rows are computed.  N (H + 2 dil)(W + 2 dil) Cin * element size < 2 GiB.
- * arseg_gemm_rows16_fwd: the same kernel as a plain GEMM on 16-bit rows (1x1 convs of the 16-bit path): out[m][co] = act(scale * x[m] . w[co] + bias
- * + residual[m][co]), x [M][K] / w [Cout][K] 16-bit (K % 64 == 0), out / residual 16-bit with row strides out_ld / res_ld.
+ * 1x1 stride-1 convolution of the 16-bit storage path as a plain GEMM of the LDS-DMA kernel (csrc/gemm_x3.hip) -- the 1x1 ConvBNReLU layers of
+ * /root/reference/model/bisenet.py:162-186,335-340,387-399: out[m][co] = act(scale[co] * x[m] . w[co] + bias[co] + residual[m][co]),
+ * x [M][K] / w [Cout][K] fp16 or bf16 (dtype: enum arseg_dtype; K % 64 == 0, dense rows), out / residual 16-bit with row strides out_ld / res_ld
+ * (elements; a channel slice of a wider tensor is fine), scale / bias fp32 (NULL: 1 / 0), Cout % 4 == 0, 16-byte aligned pointers.
+ * tile_cfg 0-11 (0-6 as arseg_gemm_x3_fwd, 7-11 narrow tiles for Cout = 64 / 128); none is chosen for the caller.
+ * (Round 5's implicit-3x3 entry points on zero-bordered rows, arseg_conv3x3_rows_fwd / arseg_pad_rows_fwd, were removed in ABI v5: never selected.)
  * ------------------------------------------------------------------------------------------- */
-enum arseg_rows_fmt { ARSEG_ROWS_X3 = 0, ARSEG_ROWS_F16 = 1, ARSEG_ROWS_BF16 = 2 };
-enum arseg_rows_out { ARSEG_ROWS_OUT_NHWC = 0, ARSEG_ROWS_OUT_PADDED = 1 };
-int arseg_conv3x3_rows_fwd(const void *x_rows, const void *w_rows, void *out, int fmt, int N, int H, int W, int Cin, int Cout, int dil,
-                           int out_mode, int out_ld, const float *scale, const float *bias, const void *residual, int res_mode, int res_ld,
-                           int act, float prelu_slope, int tile_cfg, void *range_flag, float range_limit, arseg_stream_t stream);
 int arseg_gemm_rows16_fwd(const void *x_rows, const void *w_rows, void *out, int dtype, long long M, int K, int Cout, int out_ld, const float *scale,
                           const float *bias, const void *residual, int res_ld, int act, float prelu_slope, int tile_cfg, arseg_stream_t stream);
-/* NHWC [N][H][W][C] (row stride in_ld elements; fp32 for ROWS_X3, 16-bit otherwise) -> zero-bordered rows [N][H + 2 pad][W + 2 pad][C] of format fmt.
- * One memory-bound pass; for split rows it carries the operand range watch (range_flag / range_limit as arseg_split_rows_fwd). */
-int arseg_pad_rows_fwd(const void *in, long long in_ld, void *out_rows, int fmt, int N, int H, int W, int C, int pad, void *range_flag,
-                       float range_limit, arseg_stream_t stream);
 
 /* conv3x3 (pad 1, stride 1) of a x2 bilinear (align_corners=False) upsample -- PSPUpsample, /root/reference/model/pspnet.py:43-46 --
  * by tap decomposition: since a 1x1 conv commutes with a per-channel resize, conv3x3(Up(x)) = sum_t shift_t(Up(W_t x)).  The caller

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in arseg_hip.h but not exported"
     assert sorted(_lib.PROTOTYPES) == declared, "ctypes binding and header drifted apart"
-    assert lib.arseg_version() == _lib.ABI_VERSION == 4
+    assert lib.arseg_version() == _lib.ABI_VERSION == 5
     assert b"ok" in lib.arseg_status_string(0) and b"invalid" in lib.arseg_status_string(-1)
 
 

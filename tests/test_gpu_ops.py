@@ -292,105 +292,6 @@ def test_conv2d(dev, case, conv_math):
         assert maxdiff(got, want) <= tol, (tile_cfg, split_k)
 
 
-ROWS_CASES = [
-    # N, H, W, Cin, Cout, dil, act, bn, bias, residual
-    (2, 12, 20, 64, 64, 1, "relu", True, False, True),           # ResNet BasicBlock second conv
-    (1, 9, 7, 32, 96, 2, "none", False, True, False),            # dilated, odd sizes, image smaller than a tile
-    (3, 16, 16, 128, 128, 4, "prelu", True, True, True),         # dilation 4: the border is 4 pixels wide
-    (1, 33, 65, 64, 32, 1, "relu", True, False, False),          # Cout = 32 (a partial N tile everywhere)
-    (11, 32, 64, 128, 128, 1, "relu", True, False, True),        # layer2 of the headline LR batch: many tiles, batch boundaries inside tiles
-]
-
-
-@pytest.mark.parametrize("case", ROWS_CASES, ids=lambda c: f"{c[3]}to{c[4]}d{c[5]}")
-@pytest.mark.parametrize("storage", ["x3", "f16", "bf16"])
-def test_conv3x3_rows(dev, case, storage):
-    """arseg_conv3x3_rows_fwd / arseg_pad_rows_fwd -- the 3x3 stride-1 conv as an implicit GEMM of the LDS-DMA kernel on zero-bordered rows
-    (extractors.BasicBlock, /root/reference/model/extractors.py:35-66; bisenet ConvBNReLU, bisenet.py:162-186) -- against F.conv2d in fp64:
-    every tile shape, NHWC and padded outputs, NHWC and padded residuals.  Split rows (fp32-grade): 2e-4 like every other conv test; 16-bit
-    rows: against the same conv of the ROUNDED operands (what the kernel multiplies), to fp32-accumulation accuracy + the output rounding."""
-    from arseg_amd import _lib, ops
-    from arseg_amd.packing import PackedConv
-
-    N, H, W, Cin, Cout, dil, act, use_bn, use_bias, use_res = case
-    if storage != "x3" and Cin % 64:
-        pytest.skip("16-bit rows come in groups of 64 channels")
-    g = np.random.Generator(np.random.PCG64(131))
-    sdt = {"x3": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[storage]
-    rq = (lambda a: a) if storage == "x3" else (lambda a: a.to(sdt).float())          # what a 16-bit tensor holds
-    x = rq(rnd(130, N, Cin, H, W))
-    w = rnd(132, Cout, Cin, 3, 3, scale=float(np.sqrt(2.0 / (Cin * 9))))
-    b = rnd(133, Cout, scale=0.1) if use_bias else None
-    bn = None
-    if use_bn:
-        bn = (t(g.uniform(0.5, 1.5, Cout).astype(np.float32)), rnd(134, Cout, scale=0.1), rnd(135, Cout, scale=0.1), t(g.uniform(0.5, 1.5, Cout).astype(np.float32)))
-    acts = {"none": _lib.ACT_NONE, "relu": _lib.ACT_RELU, "prelu": _lib.ACT_PRELU}
-    pc = PackedConv(w, b, bn, 1, dil, dil, acts[act], 0.2, dev)
-    res = rq(rnd(136, N, Cout, H, W)) if use_res else None
-    want = _conv_ref(x.double(), rq(w).double(), None if b is None else b.double(), None if bn is None else tuple(v.double() for v in bn), 1, dil, dil, act, 0.2,
-                     None if res is None else res.double())
-    scale = float(want.abs().max())
-    tol = 2e-4 if storage == "x3" else scale * {"f16": 1.5e-3, "bf16": 1.2e-2}[storage]      # 16-bit: the output is rounded to the storage type
-    nhwc = lambda a: a.permute(0, 2, 3, 1).contiguous().to(dev).to(sdt)      # noqa: E731
-    xp = ops.pad_rows(nhwc(x), dil)
-    assert tuple(xp.t.shape) == (N, H + 2 * dil, W + 2 * dil, Cin) and xp.shape == (N, H, W, Cin)
-    assert maxdiff(xp.interior().float().permute(0, 3, 1, 2), x) <= (4e-7 * float(x.abs().max()) if storage == "x3" else 0.0)
-    border = xp.t.clone()
-    border[:, dil:H + dil, dil:W + dil, :] = 0
-    assert float(border.view(torch.int32 if storage == "x3" else torch.int16).abs().max()) == 0
-    rd = None if res is None else nhwc(res)
-    rp = None if (res is None or Cout % (32 if storage == "x3" else 8)) else ops.pad_rows(rd, dil)
-    ran = 0
-    for cfg in range(12):
-        for out_padded in (False, True):
-            for resid in ((rd, rp) if res is not None else (None,)):
-                if resid is None and res is not None:
-                    continue
-                if out_padded and Cout % (32 if storage == "x3" else 8):
-                    continue
-                got = ops.conv3x3_rows(xp, pc, residual=resid, out_padded=out_padded, cfg=cfg)
-                if out_padded:
-                    assert isinstance(got, ops.PaddedRows) and got.pad == dil
-                    bt = got.t.clone()
-                    bt[:, dil:H + dil, dil:W + dil, :] = 0
-                    assert float(bt.view(torch.int32 if storage == "x3" else torch.int16).abs().max()) == 0, (cfg, "border not zero")
-                    got = got.interior()
-                assert got.dtype == sdt and maxdiff(got.float().permute(0, 3, 1, 2), want) <= tol, (cfg, out_padded, type(resid).__name__)
-                ran += 1
-    assert ran >= 12
-    # tuned (cfg None), writing into a channel slice of a wider buffer
-    wide = torch.zeros((N, H, W, Cout + 32), dtype=sdt, device=dev)
-    ops.conv3x3_rows(xp, pc, residual=rd, out=wide[..., 16:16 + Cout])
-    assert maxdiff(wide[..., 16:16 + Cout].float().permute(0, 3, 1, 2), want) <= tol and float(wide[..., :16].abs().max()) == 0 and float(wide[..., 16 + Cout:].abs().max()) == 0
-
-
-@pytest.mark.parametrize("storage", ["x3", "bf16"])
-def test_conv3x3_rows_block_chain(dev, storage):
-    """A BasicBlock on padded rows end to end (extractors.py:35-66): pad once, conv1 -> padded rows, conv2 + the block input as a PADDED residual ->
-    padded rows, a second block on top, un-padded only at the end -- equal to the same four convs through ops.conv2d on NHWC tensors."""
-    from arseg_amd import _lib, ops
-    from arseg_amd.packing import PackedConv
-
-    N, H, W, C = 2, 24, 40, 64
-    sdt = torch.float32 if storage == "x3" else torch.bfloat16
-    pcs = [PackedConv(rnd(140 + i, C, C, 3, 3, scale=0.04), None, (torch.ones(C), rnd(150 + i, C, scale=0.1), torch.zeros(C), torch.ones(C)), 1, 1, 1, _lib.ACT_RELU, 0.0, dev)
-           for i in range(4)]
-    x = rnd(160, N, H, W, C).to(dev).to(sdt)
-    prev = ops.configure(conv_igemm3=False)
-    try:
-        y = x
-        for i in (0, 2):
-            y = ops.conv2d(ops.conv2d(y, pcs[i]), pcs[i + 1], residual=y)
-    finally:
-        ops.configure(**prev)
-    xp = ops.pad_rows(x, 1)
-    z = xp
-    for i in (0, 2):
-        z = ops.conv3x3_rows(ops.conv3x3_rows(z, pcs[i], out_padded=True), pcs[i + 1], residual=z, out_padded=(i == 0))
-    scale = float(y.float().abs().max())
-    assert z.dtype == sdt and maxdiff(z.float(), y.float()) <= (1e-4 if storage == "x3" else 2.5e-2 * scale)
-
-
 @pytest.mark.parametrize("storage", ["f16", "bf16"])
 def test_gemm_rows16(dev, storage):
     """arseg_gemm_rows16_fwd: the 1x1 convs of the 16-bit storage path (bisenet.py FFM / SpatialPath / ARM heads) on the LDS-DMA kernel -- every
