@@ -46,7 +46,9 @@
 #define ROLL_CPRIO 2          // issue priority of the consumer waves (producers: 0)
 #endif
 #ifndef ROLL_KSLOT5
-#define ROLL_KSLOT5 1         // key ring: window row r lives in ring slot (5 r) & 7 instead of r & 7 (see kslot below)
+#define ROLL_KSLOT5 0         // 1: key ring row r lives in ring slot (5 r) & 7 instead of r & 7 (see kslot below): removes the bank conflicts of the key-block
+                              // reads across a window-row wrap -- measured (r6, same box, tools/ab_roll.sh): 0.1626-0.1627 vs 0.1617-0.1621 ms per frame,
+                              // i.e. 0.4 % SLOWER: those conflicts are not on the critical path of either half step
 #endif
 #include "warp_math.h"
 

@@ -245,7 +245,8 @@ def main():
                     "parity": r.get("parity")}
             except Exception as exc:      # a variant must never take the headline line down with it
                 result["variants"][name] = {"error": repr(exc)}
-        ops.configure(aux_outputs=bool(args.reference_outputs))
+        from arseg_amd import ops as _ops
+        _ops.configure(aux_outputs=bool(args.reference_outputs))
     if "variants" in result and "value" in result["variants"].get("psp_reference_outputs", {}):
         result["value_reference_outputs"] = result["variants"]["psp_reference_outputs"]["value"]
     if "variants" in result and "value" in result["variants"].get("psp_f32", {}):
