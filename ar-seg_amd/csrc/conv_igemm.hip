@@ -726,21 +726,27 @@ int make_plan(const arseg_conv_desc *d, Plan *pl) {
     pl->M = (int)M;
     pl->K = d->R * d->S * d->Cin;
     pl->Kpad = arseg_packed_k(d->Cin, d->R, d->S);
-    if (d->tile_cfg < 0 || d->tile_cfg > 19) return ARSEG_EINVAL;
+    if (d->tile_cfg < 0 || d->tile_cfg > 22) return ARSEG_EINVAL;
     pl->patch_tw = 0;
     if (d->tile_cfg >= 17 && d->math != ARSEG_MATH_F16X3) return ARSEG_EUNSUPPORTED;      // the large tiles are built for f16x3 only
-    if (d->tile_cfg >= 13 && d->tile_cfg <= 16) {          // patch-resident 3x3 kernel: 128 (13, 14) / 256 (15, 16) pixel tiles TH x TW of one image, BN = 64 / 128
+    // patch-resident 3x3 kernel: 128 (13, 14) / 256 (15, 16) pixel tiles TH x TW of one image, BN = 64 / 128; (r6) 20 / 21 / 22 = BN 64 on squarer
+    // tiles -- 20: 256 pixels as 8 x 32, 21: 256 as 16 x 16, 22: 128 as 8 x 16 -- whose patch has less halo than the default 4 x 64 / 2 x 64 of a
+    // wide map (340 / 324 staged pixels against 396 per 256 outputs); refused where the default tile is already that narrow
+    if ((d->tile_cfg >= 13 && d->tile_cfg <= 16) || d->tile_cfg >= 20) {
         if (d->R != 3 || d->S != 3 || d->stride != 1 || d->pad != d->dil || d->math != ARSEG_MATH_F16X3 || (d->Cin & 31) || d->batch > 1 ||
             d->split_k > 1)
             return ARSEG_EUNSUPPORTED;
         if (d->upsample2x && (d->dil != 1 || (d->H & 1) || (d->W & 1))) return ARSEG_EUNSUPPORTED;
-        const int bm = d->tile_cfg >= 15 ? 256 : 128;
-        const int tw = pl->Wo >= 48 ? 64 : (pl->Wo >= 24 ? 32 : 16), th = bm / tw;
+        const int bm = (d->tile_cfg == 13 || d->tile_cfg == 14 || d->tile_cfg == 22) ? 128 : 256;
+        int tw = pl->Wo >= 48 ? 64 : (pl->Wo >= 24 ? 32 : 16);
+        if (d->tile_cfg == 20) { if (tw <= 32) return ARSEG_EUNSUPPORTED; tw = 32; }
+        if (d->tile_cfg >= 21) { if (tw <= 16) return ARSEG_EUNSUPPORTED; tw = 16; }
+        const int th = bm / tw;
         if ((th + 2 * d->dil) * (tw + 2 * d->dil) > (bm == 128 ? 288 : 448)) return ARSEG_EUNSUPPORTED;
         if (((long long)d->N * d->H * d->W * d->in_ld + d->Cin) * 4 >= (1ll << 31) || (long long)d->Cout * pl->Kpad * 4 >= (1ll << 31))
             return ARSEG_EUNSUPPORTED;
         pl->patch_tw = tw;
-        pl->bm = bm; pl->bn = (d->tile_cfg & 1) ? 64 : 128; pl->bk = 32; pl->nbuf = 2;
+        pl->bm = bm; pl->bn = (d->tile_cfg >= 20 || (d->tile_cfg & 1)) ? 64 : 128; pl->bk = 32; pl->nbuf = 2;
         pl->ktiles = pl->Kpad / 32; pl->ktiles_per_split = pl->ktiles; pl->nsplit = 1;
         pl->tiles_m = d->N * arseg_cdiv(pl->Ho, th) * arseg_cdiv(pl->Wo, tw);
         pl->tiles_n = arseg_cdiv(d->Cout, pl->bn);
@@ -1032,11 +1038,12 @@ int find_candidates(const arseg_conv_desc *d, FindCand *c, int cap) {
     c[n++] = FindCand{0, 0};
     if (d->upsample2x) {                       // only the patch-resident plans upsample while they stage
         for (int cfg = 13; cfg <= 16 && n < cap; ++cfg) c[n++] = FindCand{cfg, 1};
+        for (int cfg = 20; cfg <= 22 && n < cap; ++cfg) c[n++] = FindCand{cfg, 1};
         return n;
     }
     const int ktiles = (d->R * d->S * d->Cin + 31) / 32;
-    for (int cfg = 5; cfg <= 19 && n < cap; ++cfg) {
-        if (cfg >= 13 && cfg <= 16) { c[n++] = FindCand{cfg, 1}; continue; }
+    for (int cfg = 5; cfg <= 22 && n < cap; ++cfg) {
+        if ((cfg >= 13 && cfg <= 16) || cfg >= 20) { c[n++] = FindCand{cfg, 1}; continue; }
         static const int sks[6] = {1, 2, 3, 4, 6, 8};
         for (int i = 0; i < 6 && n < cap; ++i) {
             const int sk = sks[i];

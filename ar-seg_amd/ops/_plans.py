@@ -39,13 +39,13 @@ class _PlanCache(dict):
 
 _conv_plans = _PlanCache()
 _config._plan_file_listeners.append(_conv_plans.load)
-_PATCH_CFGS = (13, 14, 15, 16)      # arseg_conv_desc.tile_cfg of the patch-resident 3x3 kernel (the only direct plans with a fused x2 upsample)
+_PATCH_CFGS = (13, 14, 15, 16, 20, 21, 22)      # arseg_conv_desc.tile_cfg of the patch-resident 3x3 kernel (the only direct plans with a fused x2 upsample)
 
 
 def _conv_candidates(ktiles: int, cout: int, m: int, patch_ok: bool = False):
     cands = []
     if patch_ok:                                   # patch-resident 3x3 kernel (13/14: 128-pixel tiles, 15/16: 256; BN 64/128)
-        cands += [(15, 1), (13, 1)] + ([(16, 1), (14, 1)] if cout > 64 else [])
+        cands += [(15, 1), (13, 1), (20, 1), (21, 1), (22, 1)] + ([(16, 1), (14, 1)] if cout > 64 else [])      # 20..22: squarer 64-channel tiles (r6)
     for cfg in (5, 6, 7, 8, 9, 10, 11, 12) + ((17, 18, 19) if sw.math == _lib.MATH_F16X3 else ()):
         bn = {17: 128, 18: 256, 19: 256}.get(cfg, 128 if cfg in (5, 8, 9, 12) else 64)
         bm = {17: 256, 18: 128, 19: 256}.get(cfg, 128 if cfg in (5, 6, 9, 10) else 64)

@@ -401,11 +401,12 @@ def _conv2d16(x, pc, residual, out, up2, tile_cfg=0, split_k=0):
         if plan is None:
             best_t = float("inf")
             ktiles = (pc.R * pc.S * Cin + 63) // 64
-            for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9):    # 5..8: patch-resident 3x3 plans, 9: the 7x7 stem kernel (EUNSUPPORTED for other shapes)
+            # 5..8, 10..13: patch-resident 3x3 plans (10..13: squarer pixel tiles, r6), 9: the 7x7 stem kernel (EUNSUPPORTED for other shapes)
+            for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13):
                 for sk in (0, 1, 2, 4, 8):
                     if sk > 1 and (ktiles // sk < 3 or pc.cout % 8 or cfg >= 5):
                         continue
-                    if cfg >= 5 and (sk == 1 or (cfg in (6, 8) and pc.cout <= 64)):
+                    if cfg >= 5 and (sk == 1 or (cfg in (6, 8, 12) and pc.cout <= 64)):
                         continue
                     d.tile_cfg, d.split_k = cfg, sk
                     try:

@@ -187,7 +187,9 @@ typedef struct arseg_conv_desc {
                           13..16 = patch-resident kernel for 3x3 stride-1 pad==dil convs under ARSEG_MATH_F16X3 (Cin % 32 == 0): the
                           input patch of a 128- (13, 14) or 256-pixel (15, 16) tile stays in LDS for all nine taps, BN = 64 / 128;
                           ARSEG_EUNSUPPORTED for other shapes; 17..19 = 256x128, 128x256, 256x256 tiles on 8 / 16 waves (F16X3 only):
-                          more MFMA work per byte fetched from L2 / Infinity Cache, for wide GEMMs that fill the chip */
+                          more MFMA work per byte fetched from L2 / Infinity Cache, for wide GEMMs that fill the chip; 20..22 (r6) = the
+                          patch-resident kernel with BN = 64 on squarer pixel tiles (20: 256 pixels as 8 x 32, 21: 16 x 16, 22: 128 pixels as
+                          8 x 16: less halo per output than the 4 x 64 / 2 x 64 tiles 13..16 take on a wide map); refused on narrower maps */
     int split_k;       /* 0 auto, >= 1 explicit */
     /* batched mode (used by the Winograd path): `batch` independent problems of identical shape, problem b reads
        in + b*in_batch_stride, w_packed + b*w_batch_stride and writes out + b*out_batch_stride (strides in floats);
@@ -419,13 +421,23 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  *   arseg_conv2d16_fwd: desc as arseg_conv2d_fwd (tile_cfg: 0 auto; 1 / 2 = 64- / 128-channel tile with K step 32; 3 / 4 = the same with
  *                       K step 64; 5..8 = patch-resident kernel for 3x3 stride-1 pad == dil convs with Cin % 64 == 0 (the input patch of a
  *                       128- (5, 6) / 256-pixel (7, 8) tile stays in LDS for all nine taps, 64 / 128 output channels; no split-K;
- *                       ARSEG_EUNSUPPORTED for other shapes); 9 = stem kernel (7x7 stride 2 pad 3, NHWC8 -> 64 channels, no residual: all weights
+ *                       ARSEG_EUNSUPPORTED for other shapes; 10..13 = the same kernel on squarer pixel tiles -- 10: 256 pixels as 8 x 32, 64 channels;
+ *                       11: 16 x 16, 64 channels; 12: 8 x 32, 128 channels; 13: 128 pixels as 8 x 16, 64 channels -- refused on maps whose
+ *                       default tile is already that narrow); 9 = stem kernel (7x7 stride 2 pad 3, NHWC8 -> 64 channels, no residual: all weights
  *                       resident in LDS, one staged input patch per 8x32 output tile); split_k: 0 = automatic -- K slices for launches whose tiles do not fill the chip, e.g. the 16x32-map
  *                       layers of BiSeNet-18 --, >= 1 explicit; deterministic: fp32 partial sums in `workspace`
  *                       (arseg_conv2d16_workspace_bytes(desc) bytes, 0 without split-K), summed in slice order by a second kernel that
  *                       applies the epilogue; split-K needs Cout % 8 == 0, otherwise one slice.  batch unused)
+ *   arseg_stem_pool16_fwd (r6): the ResNet-18 stem of the 16-bit path in ONE launch -- conv1 (7x7 stride 2 pad 3, 3 -> 64; the frame as NHWC8)
+ *                       -> folded bn1 -> activation -> MaxPool2d(3, 2, 1) (/root/reference/model/bisenet.py:75-78,86-89).  in: [N][H][W][in_ld]
+ *                       16-bit (in_ld % 8 == 0, channels 3..7 zero), w_packed16: the stem's arseg_pack_conv_weight16_host image (Cin_pad 8),
+ *                       out: [N][Hp][Wp][out_ld] with Hp = (Ho - 1) / 2 + 1, Ho = (H - 1) / 2 + 1 (likewise W); scale / bias fp32 [64] or NULL.
+ *                       Bit-identical to arseg_maxpool3x3s2_16_fwd(arseg_conv2d16_fwd(tile_cfg 9)): the conv output is rounded to 16 bits once, in LDS,
+ *                       and never written to HBM (184 MB per 11-frame 512x1024 batch).
  * ------------------------------------------------------------------------------------------- */
 int arseg_packed_k16(int Cin_pad, int R, int S);
+int arseg_stem_pool16_fwd(int dtype, const void *in_nhwc8, const void *w_packed16, const float *scale, const float *bias, void *out, int N, int H,
+                          int W, int in_ld, int out_ld, int act, float prelu_slope, arseg_stream_t stream);
 int arseg_pack_conv_weight16_host(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host);
 size_t arseg_conv2d16_workspace_bytes(const arseg_conv_desc *d);
 int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,

@@ -728,8 +728,12 @@ def test_conv2d_fused_upsample(dev, N, h, w, Cin, Cout, conv_math):
     if conv_math == "f16x3":
         # patch-resident plans: the upsample is applied while the input patch is staged (one low-resolution quad per 2 x 2 block of
         # the patch); must equal the materialised upsample + the same kernel, edges and odd sizes included
-        for cfg in (13, 15) + ((14, 16) if Cout > 64 else ()):
-            got3 = ops.conv2d(xd, pc, up2=True, tile_cfg=cfg, split_k=1)
+        for cfg in (13, 15) + ((14, 16) if Cout > 64 else ()) + (20, 21, 22):      # 20..22: the squarer tiles of round 6 (refused on narrow maps)
+            try:
+                got3 = ops.conv2d(xd, pc, up2=True, tile_cfg=cfg, split_k=1)
+            except _lib.ArsegError:
+                assert cfg >= 20 and 2 * w < 48, cfg
+                continue
             assert maxdiff(got3.permute(0, 3, 1, 2), want) <= 2e-4, cfg
             mat = ops.conv2d(ops.resize_nhwc(xd, 2 * h, 2 * w, _lib.BILINEAR, False), pc, tile_cfg=cfg, split_k=1)
             assert maxdiff(got3, mat) <= 1e-5, cfg
