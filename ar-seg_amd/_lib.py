@@ -61,7 +61,6 @@ PROTOTYPES = {
     "arseg_conv2d_find": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_float), _STREAM]),
     "arseg_psp_w2_split_fwd": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_float, _STREAM]),
     "arseg_creff_warp_select": (c_int, [c_int] * 12),
-    "arseg_stem_pool16_fwd": (c_int, [c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_float, _STREAM]),
     "arseg_peak_stream_copy": (c_int, [_P, _P, c_size_t, _STREAM]),
     "arseg_peak_mfma_f16": (c_int, [_P, c_int, POINTER(c_double), _STREAM]),
     "arseg_gemm_rows16_fwd": (c_int, [_P, _P, _P, c_int, c_int64, c_int, c_int, c_int, _P, _P, _P, c_int, c_int, c_float, c_int, _STREAM]),

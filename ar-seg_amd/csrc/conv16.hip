@@ -553,164 +553,6 @@ int launch_stem16(const Conv16Params &p, hipStream_t st) {
     return arseg_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------
-// (r6) Stem + max-pool in one kernel: conv1 (7x7 stride 2 pad 3, NHWC8 -> 64 channels) -> folded BN -> activation -> MaxPool2d(3, 2, 1)
-// (model/bisenet.py:75-78,86-89: Resnet18.conv1 / bn1 / relu / maxpool).  The two-launch form writes the 64-channel conv output
-// (184 MB per 11-frame LR batch) and reads it back to keep a quarter of it; here the conv output lives in LDS for the duration of a tile.
-//   * the GEMM of conv16_stem_kernel (all weights resident in LDS, one staged input patch per tile, two taps per K step), on a 16 x 32 conv tile
-//     with 8 waves;
-//   * a workgroup owns a strip of 15 pooled columns (conv columns 30t - 1 .. 30t + 30: two conv columns are computed by both neighbours -- a
-//     pooled column needs conv columns 2px - 1 .. 2px + 1, and 32 conv columns hold 15 such triples whole) and walks DOWN it 16 conv rows at a
-//     time; the last conv row of a tile is carried to the next one in LDS (pooled row py needs conv rows 2py - 1 .. 2py + 1), so rows are never
-//     recomputed inside a segment; a segment that does not start at the image top first runs one tile above itself with its stores off;
-//   * epilogue: accumulators -> scale / bias / activation -> ONE rounding to 16 bits (the value the two-launch form stores) -> LDS tile ->
-//     3 x 3 max over the 16-bit values (taps outside the conv image are skipped: MaxPool2d pads with -inf) -> 16-byte NHWC stores.
-// Bit-identical to arseg_maxpool3x3s2_16_fwd(arseg_conv2d16_fwd(tile_cfg 9)).
-template <bool BF>
-__global__ __launch_bounds__(512) void conv16_stem_pool_kernel(const Conv16Params p, const int Hp, const int Wp, const int nstrips, const int nseg, const int seg_tiles) {
-    constexpr int TH = 16, TW = 32, PH = 2 * TH + 5, PW = 2 * TW + 5, PLN = (PW + 1) / 2, PROW = 2 * PLN;     // 37 x 69 patch, 35-piece planes
-    constexpr int WROW = 51;
-    constexpr int OPX = 144, OROW = TW * OPX;                 // conv tile in LDS: 144 bytes per pixel (64 channels + pad: 16-byte aligned, 2-way on the writes at most)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    u32x4 *Wl = reinterpret_cast<u32x4 *>(smem);                        // [64][WROW]
-    f32x4 *SBl = reinterpret_cast<f32x4 *>(Wl + 64 * WROW);              // [16] scale | [16] bias
-    unsigned char *Cr = reinterpret_cast<unsigned char *>(SBl + 32);     // [2][TW][OPX] carried conv row (ping-pong by tile parity)
-    unsigned char *U = Cr + 2 * OROW;                                    // union: input patch [PH][2][PLN] u32x4  |  conv tile [TH][TW][OPX]
-    u32x4 *Pl = reinterpret_cast<u32x4 *>(U);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
-    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t *>(p.in), 0, (int)p.in_bytes, 0x00020000);
-    for (int i = tid; i < 64 * 50; i += 512) {
-        const int co = i / 50, t = i - co * 50;
-        Wl[co * WROW + t] = *reinterpret_cast<const u32x4 *>(p.w + (size_t)co * p.Kpad + t * 8);
-    }
-    if (tid < 128) reinterpret_cast<float *>(SBl)[tid] = tid < 64 ? (p.scale ? p.scale[tid] : 1.0f) : (p.bias ? p.bias[tid - 64] : 0.0f);
-    // unit = (image, strip, row segment)
-    const int unit = blockIdx.x, img = unit / (nstrips * nseg), ur = unit - img * (nstrips * nseg), strip = ur / nseg, seg = ur - strip * nseg;
-    const int c0 = 30 * strip - 1;                            // first conv column of the strip's tiles
-    const int rt_all = (p.Ho + TH - 1) / TH;                  // row tiles of the image
-    const int rt0 = seg * seg_tiles, rt1 = min(rt_all, rt0 + seg_tiles);
-    const int it0 = rt0 > 0 ? rt0 - 1 : 0;                    // (a priming tile above the segment: only its last conv row is kept)
-    constexpr int NIT = (PH * PW + 511) / 512;                // 5
-    u32x4 pre[NIT];
-    auto patch_load = [&](int rt) {
-        const int py0 = 2 * (rt * TH) - 3, px0 = 2 * c0 - 3;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 512, row = i / PW, c = i - row * PW, gy = py0 + row, gx = px0 + c;
-            const bool ok = i < PH * PW && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-            pre[it] = __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, ok ? (unsigned)(((img * p.H + gy) * p.W + gx) * p.in_ld) * 2u : OOB, 0, 0);
-        }
-    };
-    auto patch_store = [&]() {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int i = tid + it * 512, row = i / PW, c = i - row * PW;
-            if (i < PH * PW) Pl[row * PROW + (c & 1) * PLN + (c >> 1)] = pre[it];
-        }
-    };
-    if (it0 < rt1) patch_load(it0);
-    for (int rt = it0; rt < rt1; ++rt) {
-        const bool emit = rt >= rt0;
-        const int r0 = rt * TH, par = rt & 1;
-        __syncthreads();                                      // the previous tile's conv tile is no longer read (and the weights are in place)
-        patch_store();
-        __syncthreads();
-        if (rt + 1 < rt1) patch_load(rt + 1);
-        f32x16 acc[2][2];                                     // [co tile][conv row of the wave]
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-#pragma unroll 5
-        for (int j = 0; j < 25; ++j) {
-            const int t = 2 * j + lh, tc = min(t, 48), r = (tc * 37) >> 8, sx = tc - 7 * r;
-            u32x4 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = Wl[(32 * i + li) * WROW + t];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) b[i] = Pl[(2 * (2 * wave + i) + r) * PROW + (sx & 1) * PLN + li + (sx >> 1)];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) acc[i][k] = mfma16<BF>(a[i], b[k], acc[i][k]);
-        }
-        __syncthreads();                                      // everybody is done with the patch: the union becomes the conv tile
-        // conv tile: lane = pixel (column li of conv row 2 * wave + k), accumulator rows = channels (e & 3) + 8 * (e >> 2) + 4 * lh (+ 32 i)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            unsigned char *dst = U + (2 * wave + k) * OROW + li * OPX;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                    const int co = 32 * i + 8 * q4 + 4 * lh;
-                    const f32x4 sc = SBl[co >> 2], bi = SBl[16 + (co >> 2)];
-                    uint16_t o[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = arseg_f2h<BF>(act_apply(acc[i][k][4 * q4 + e] * sc[e] + bi[e], p.act, p.slope));
-                    *reinterpret_cast<u32x2 *>(dst + co * 2) = u32x2{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16)};
-                }
-        }
-        __syncthreads();
-        // the last conv row of the tile travels to the next one (the other half of the ping-pong: this tile still reads its own carry below)
-        if (tid < TW * 8) *reinterpret_cast<u32x4 *>(Cr + (par ^ 1) * OROW + (tid >> 3) * OPX + (tid & 7) * 16) =
-            *reinterpret_cast<const u32x4 *>(U + (TH - 1) * OROW + (tid >> 3) * OPX + (tid & 7) * 16);
-        if (emit) {
-            // pooled rows py = r0 / 2 + pr (pr 0..7) from conv rows r0 - 1 + 2 pr + {0, 1, 2} (index 0 = the carried row), pooled columns
-            // px = 15 strip + q (q 0..14) from tile columns 2q + {0, 1, 2}; 8 channels per item
-            for (int it = tid; it < 8 * 15 * 8; it += 512) {
-                const int c8 = it & 7, pq = it >> 3, pr = pq / 15, q = pq - 15 * pr;
-                const int py = (r0 >> 1) + pr, px = 15 * strip + q;
-                if (py >= Hp || px >= Wp) continue;
-                float m[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
-#pragma unroll
-                for (int dr = 0; dr < 3; ++dr) {
-                    const int R = 2 * pr + dr, gr = r0 - 1 + R;                    // tile row index (0 = carry), conv row
-                    if ((unsigned)gr >= (unsigned)p.Ho) continue;
-                    const unsigned char *rowp = R == 0 ? Cr + par * OROW : U + (R - 1) * OROW;
-#pragma unroll
-                    for (int dc = 0; dc < 3; ++dc) {
-                        const int c = 2 * q + dc;
-                        if ((unsigned)(c0 + c) >= (unsigned)p.Wo) continue;
-                        const u32x4 v = *reinterpret_cast<const u32x4 *>(rowp + c * OPX + c8 * 16);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e)
-                            m[e] = fmaxf(m[e], arseg_h2f<BF>((uint16_t)((e & 1) ? v[e >> 1] >> 16 : v[e >> 1] & 0xffffu)));
-                    }
-                }
-                uint16_t o[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = arseg_f2h<BF>(m[e]);             // (exact: the maximum is one of the 16-bit inputs)
-                *reinterpret_cast<u32x4 *>(p.out + (((size_t)img * Hp + py) * Wp + px) * p.out_ld + c8 * 8) =
-                    u32x4{o[0] | ((unsigned)o[1] << 16), o[2] | ((unsigned)o[3] << 16), o[4] | ((unsigned)o[5] << 16), o[6] | ((unsigned)o[7] << 16)};
-            }
-        }
-    }
-}
-
-template <bool BF>
-int launch_stem_pool16(const Conv16Params &p, int Hp, int Wp, hipStream_t st) {
-    constexpr size_t U_BYTES = (size_t)16 * 32 * 144;                                   // conv tile (73,728) >= patch (37 x 70 x 16 = 41,440)
-    const size_t smem = (size_t)64 * 51 * 16 + 32 * 16 + (size_t)2 * 32 * 144 + U_BYTES;
-    static ArsegSmemAttr attr;
-    if (int e = arseg_allow_smem(attr, reinterpret_cast<const void *>(conv16_stem_pool_kernel<BF>), smem)) return e;
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    const int nstrips = arseg_cdiv(Wp, 15), rt_all = arseg_cdiv(p.Ho, 16);
-    // row segments: as many as still give one round of workgroups (a segment pays one priming tile), at least 3 row tiles each
-    int nseg = cus / (p.N * nstrips);
-    nseg = nseg < 1 ? 1 : nseg;
-    if (nseg > rt_all / 3) nseg = rt_all / 3 > 0 ? rt_all / 3 : 1;
-    const int seg_tiles = arseg_cdiv(rt_all, nseg);
-    nseg = arseg_cdiv(rt_all, seg_tiles);
-    hipLaunchKernelGGL((conv16_stem_pool_kernel<BF>), dim3(p.N * nstrips * nseg), dim3(512), smem, st, p, Hp, Wp, nstrips, nseg, seg_tiles);
-    return arseg_launch_status();
-}
-
 // sums the split-K partials in slice order and applies the epilogue (scale, bias, residual, activation, one rounding to 16 bits);
 // 8 channels per thread (Cout % 8 == 0 with split-K)
 template <bool BF>
@@ -861,25 +703,4 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     p.tiles_co = arseg_cdiv(d->Cout, co_t); p.tiles_px = arseg_cdiv(M, PIX_T);
     hipStream_t st = arseg_stream(stream);
     return dtype == ARSEG_DT_BF16 ? launch_cfg<true>(p, wide, deep, st) : launch_cfg<false>(p, wide, deep, st);
-}
-
-// (r6) conv1 -> bn1 -> relu -> maxpool of the 16-bit ResNet-18 stem in one launch (model/bisenet.py:75-78,86-89); see conv16_stem_pool_kernel.
-extern "C" int arseg_stem_pool16_fwd(int dtype, const void *in_nhwc8, const void *w_packed16, const float *scale, const float *bias, void *out,
-                                     int N, int H, int W, int in_ld, int out_ld, int act, float prelu_slope, arseg_stream_t stream) {
-    ARSEG_CHECK_PTR(in_nhwc8); ARSEG_CHECK_PTR(w_packed16); ARSEG_CHECK_PTR(out);
-    ARSEG_CHECK_POS(N); ARSEG_CHECK_POS(H); ARSEG_CHECK_POS(W);
-    if (dtype != ARSEG_DT_F16 && dtype != ARSEG_DT_BF16) return ARSEG_EINVAL;
-    if (in_ld < 8 || (in_ld & 7) || out_ld < 64 || (out_ld & 7)) return ARSEG_EINVAL;
-    if (!ARSEG_ALIGNED16(in_nhwc8) || !ARSEG_ALIGNED16(w_packed16) || !ARSEG_ALIGNED16(out)) return ARSEG_EINVAL;
-    Conv16Params p;
-    p.in = (const uint16_t *)in_nhwc8; p.w = (const uint16_t *)w_packed16; p.res = nullptr; p.scale = scale; p.bias = bias; p.out = (uint16_t *)out;
-    p.N = N; p.H = H; p.W = W; p.Cin = 8; p.in_ld = in_ld; p.Ho = (H + 2 * 3 - 7) / 2 + 1; p.Wo = (W + 2 * 3 - 7) / 2 + 1; p.Cout = 64; p.out_ld = out_ld; p.res_ld = 0;
-    p.R = 7; p.S = 7; p.stride = 2; p.pad = 3; p.dil = 1; p.K = 49 * 8; p.Kpad = (p.K + KPAD - 1) / KPAD * KPAD; p.act = act; p.slope = prelu_slope;
-    const int Hp = (p.Ho - 1) / 2 + 1, Wp = (p.Wo - 1) / 2 + 1;                           // MaxPool2d(kernel 3, stride 2, padding 1)
-    const size_t in_bytes = (size_t)N * H * W * in_ld * 2, w_bytes = (size_t)64 * p.Kpad * 2;
-    if (in_bytes >= (1ull << 31) || (size_t)N * Hp * Wp * out_ld * 2 >= (1ull << 31)) return ARSEG_EUNSUPPORTED;
-    p.M = N * p.Ho * p.Wo; p.in_bytes = (unsigned)in_bytes; p.w_bytes = (unsigned)w_bytes;
-    p.patch_tw = 0; p.patch_l2tw = 0; p.tiles_m = 0; p.tiles_co = 1; p.tiles_px = 0; p.nsplit = 1; p.kt_per_split = 0; p.ws = nullptr;
-    hipStream_t st = arseg_stream(stream);
-    return dtype == ARSEG_DT_BF16 ? launch_stem_pool16<true>(p, Hp, Wp, st) : launch_stem_pool16<false>(p, Hp, Wp, st);
 }

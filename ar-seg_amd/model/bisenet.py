@@ -76,10 +76,7 @@ class Resnet18(HipModule):
         return PackedConv.from_modules(self.conv1, self.bn1, _lib.ACT_RELU, device=device)
 
     def forward_nhwc(self, x4):
-        if ops.is16(x4) and x4.shape[-1] == 8 and ops.config.stem_pool_fused:
-            x = ops.stem_pool16(x4, self.packed())          # conv1 -> bn1 -> relu -> maxpool in one launch (bit-identical to the two below)
-        else:
-            x = ops.maxpool3x3s2(ops.conv2d(x4, self.packed()))
+        x = ops.maxpool3x3s2(ops.conv2d(x4, self.packed()))
         for blk in self.layer1:
             x = blk.forward_nhwc(x)
         feats = []

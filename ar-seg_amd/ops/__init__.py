@@ -25,7 +25,7 @@ from .conv import (SplitRows, _conv1x1_x3, _conv2d16, _conv_up2_taps, _conv_wino
                    psp_bottleneck_x3, psp_x3_foldable, split_rows)
 from .creff import creff, creff_warp, creff_warp_kernel, flow_resize, mv_resize, warp, warp_mvq
 from .layers import (adaptive_avgpool, argmax_confusion, as_nchw, cast, frame_ingest, frame_to_nhwc4, frame_u8_to_nhwc4, from_c8, global_reduce, head,
-                     is_nhwc_view, local_similar, local_weighting, maxpool3x3s2, stem_pool16, merge_motion, psp_pool_matrix, psp_prior_sum, resize_nchw, resize_nhwc,
+                     is_nhwc_view, local_similar, local_weighting, maxpool3x3s2, merge_motion, psp_pool_matrix, psp_prior_sum, resize_nchw, resize_nhwc,
                      scale_add, to_c8, to_nchw_contiguous, to_nhwc)
 
 _LEGACY_SWITCHES = {"_AUTOTUNE": "AUTOTUNE", "_math": "math", "_RANGE_MODE": "RANGE_MODE", "_RANGE_GUARD": "RANGE_GUARD", "_NATIVE_FIND": "NATIVE_FIND",

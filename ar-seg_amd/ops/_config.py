@@ -56,8 +56,6 @@ class Config:
     lr_subbatch      [ARSEG_LR_SUBBATCH = n]                    evaluate the LR batch of a GOP in slices of n frames (bounds the working set)
     aux_outputs      [ARSEG_AUX_OUTPUTS = 0 | 1]                the fast paths (evaluation.alter_res_*) also evaluate the training-only auxiliary outputs that
                      forward_phase1 returns and evaluation.py:190-191 discards (default 0: skipped; forward() / forward_phase1() always return them)
-    stem_pool_fused  [ARSEG_STEM_POOL_FUSED = 1 | 0]            16-bit path: conv1 -> bn1 -> relu -> maxpool of the ResNet-18 stem in one launch (bit-identical to the
-                     two-launch form; 0 = the stem kernel + the max-pool kernel of rounds 2-5)
     (ARSEG_HIP_LIB = <path> selects an alternative library build; it is read by _lib before anything is loaded.)"""
     conv_math: str = "f16x3"
     conv_autotune: bool = True
@@ -76,7 +74,6 @@ class Config:
     creff_max_wgs: int = 0
     lr_subbatch: int = 0
     aux_outputs: bool = False
-    stem_pool_fused: bool = True
 
     @classmethod
     def from_env(cls):
@@ -100,7 +97,7 @@ class Config:
                 conv_plan_file=e("ARSEG_CONV_PLAN_FILE"), creff_impl=e("ARSEG_CREFF_IMPL", ""), creff_tile_rows=num("ARSEG_CREFF_TY", int, 0),
                 creff_warp_impl=e("ARSEG_CREFF_WARP_IMPL", ""), creff_seg_rows=num("ARSEG_CREFF_SEG_ROWS", int, 0),
                 creff_max_wgs=num("ARSEG_CREFF_MAX_WGS", int, 0), lr_subbatch=num("ARSEG_LR_SUBBATCH", int, 0),
-                aux_outputs=e("ARSEG_AUX_OUTPUTS", "0") not in ("", "0"), stem_pool_fused=e("ARSEG_STEM_POOL_FUSED", "1") != "0")
+                aux_outputs=e("ARSEG_AUX_OUTPUTS", "0") not in ("", "0"))
         validate(dataclasses.asdict(c), source="environment")
         return c
 

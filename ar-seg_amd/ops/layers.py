@@ -154,24 +154,6 @@ def maxpool3x3s2(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def stem_pool16(x8: torch.Tensor, pc) -> torch.Tensor:
-    """conv1 (7x7 stride 2 pad 3) -> folded bn1 -> activation -> MaxPool2d(3, 2, 1) of the 16-bit ResNet-18 stem in ONE launch
-    (arseg_stem_pool16_fwd; model/bisenet.py:75-78,86-89): x8 NHWC8 fp16 / bf16 frame, pc the stem's PackedConv.  Bit-identical to
-    maxpool3x3s2(conv2d(x8, pc)); the 64-channel conv output never reaches HBM."""
-    dt = _need_gpu16(x8)
-    N, H, W, C = x8.shape
-    w16, cin16 = pc.weights16(x8.dtype)
-    if C != 8 or cin16 != 8 or pc.R != 7 or pc.S != 7 or pc.stride != 2 or pc.pad != 3 or pc.dil != 1 or pc.cout != 64:
-        raise _lib.ArsegError("stem_pool16: the 7x7 stride-2 pad-3 stem on an NHWC8 frame with 64 output channels is required")
-    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = torch.empty((N, (Ho - 1) // 2 + 1, (Wo - 1) // 2 + 1, 64), dtype=x8.dtype, device=x8.device)
-    flops = 2 * N * Ho * Wo * 64 * 49 * pc.cin
-    with tagged((N, H, W, pc.cin, 64, 7, 2, 1, False, "16-bit stem+pool", flops)):
-        launch("conv2d", _lib.load().arseg_stem_pool16_fwd, dt, _ptr(x8), _ptr(w16), _ptr(pc.scale), _ptr(pc.bias), _ptr(out), N, H, W,
-               _nhwc_ld(x8), 64, pc.act, pc.slope, _stream(), flops=flops)
-    return out
-
-
 def adaptive_avgpool(x: torch.Tensor, oh: int, ow: int, out: Optional[torch.Tensor] = None, out_ld: int = 0, out_n_stride: int = 0
                      ) -> torch.Tensor:
     """NHWC -> [N,oh,ow,C]; or, with ``out`` (a base tensor/view whose data_ptr is the first bin of image 0), into rows of a

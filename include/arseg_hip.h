@@ -428,16 +428,8 @@ int arseg_nhwc_to_nchw_fwd(const float *in, int in_ld, float *out, int N, int C,
  *                       layers of BiSeNet-18 --, >= 1 explicit; deterministic: fp32 partial sums in `workspace`
  *                       (arseg_conv2d16_workspace_bytes(desc) bytes, 0 without split-K), summed in slice order by a second kernel that
  *                       applies the epilogue; split-K needs Cout % 8 == 0, otherwise one slice.  batch unused)
- *   arseg_stem_pool16_fwd (r6): the ResNet-18 stem of the 16-bit path in ONE launch -- conv1 (7x7 stride 2 pad 3, 3 -> 64; the frame as NHWC8)
- *                       -> folded bn1 -> activation -> MaxPool2d(3, 2, 1) (/root/reference/model/bisenet.py:75-78,86-89).  in: [N][H][W][in_ld]
- *                       16-bit (in_ld % 8 == 0, channels 3..7 zero), w_packed16: the stem's arseg_pack_conv_weight16_host image (Cin_pad 8),
- *                       out: [N][Hp][Wp][out_ld] with Hp = (Ho - 1) / 2 + 1, Ho = (H - 1) / 2 + 1 (likewise W); scale / bias fp32 [64] or NULL.
- *                       Bit-identical to arseg_maxpool3x3s2_16_fwd(arseg_conv2d16_fwd(tile_cfg 9)): the conv output is rounded to 16 bits once, in LDS,
- *                       and never written to HBM (184 MB per 11-frame 512x1024 batch).
  * ------------------------------------------------------------------------------------------- */
 int arseg_packed_k16(int Cin_pad, int R, int S);
-int arseg_stem_pool16_fwd(int dtype, const void *in_nhwc8, const void *w_packed16, const float *scale, const float *bias, void *out, int N, int H,
-                          int W, int in_ld, int out_ld, int act, float prelu_slope, arseg_stream_t stream);
 int arseg_pack_conv_weight16_host(const float *w_oihw_host, int Cout, int Cin, int R, int S, int Cin_pad, int dtype, void *out_host);
 size_t arseg_conv2d16_workspace_bytes(const arseg_conv_desc *d);
 int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const void *in, const void *w_packed16, const float *scale,

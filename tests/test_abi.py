@@ -61,7 +61,9 @@ def test_entry_points_reject_bad_arguments_without_a_gpu():
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # f16x3 only
     d.tile_cfg, d.math = 17, _lib.MATH_F32
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED       # 8/16-wave tiles: f16x3 only
-    d.tile_cfg, d.math = 20, _lib.MATH_F16X3
+    d.tile_cfg, d.math = 20, _lib.MATH_F16X3          # (r6) 20..22: the squarer patch tiles -- refused on this 8-pixel-wide map, whose default tile is already narrow
+    assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EUNSUPPORTED
+    d.tile_cfg = 23
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL
     d.tile_cfg, d.math = 0, 7
     assert lib.arseg_conv_out_hw(ctypes.byref(d), ctypes.byref(ho), ctypes.byref(wo)) == _lib.ARSEG_EINVAL

@@ -114,37 +114,6 @@ def test_conv2d16(dev, case, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 33, 47), (1, 400, 64), (1, 70, 150), (3, 130, 258)], ids=lambda s: "x".join(map(str, s)))
-def test_stem_pool16(dev, dtype, shape):
-    """arseg_stem_pool16_fwd (conv1 -> bn1 -> relu -> maxpool of bisenet.py:75-78,86-89 in one launch) == the stem kernel followed by the max-pool
-    kernel, bit for bit, and both within the 16-bit bound of an fp64 reference: whole tiles, ragged maps, several column strips (15 pooled columns
-    each, two conv columns shared with the neighbour), row segments with a priming tile (the 400-row case), a batch, ReLU and no activation
-    (negative values under the max)."""
-    from arseg_amd import _lib, ops
-    from arseg_amd.packing import PackedConv
-
-    N, H, W = shape
-    x = rnd(11, N, 3, H, W).to(dtype)
-    w = rnd(12, 64, 3, 7, 7, scale=(2.0 / 147) ** 0.5)
-    g = np.random.Generator(np.random.PCG64(13))
-    bnp = (t(g.uniform(0.75, 1.25, 64).astype(np.float32)), rnd(14, 64, scale=0.1), rnd(15, 64, scale=0.1), t(g.uniform(0.5, 1.5, 64).astype(np.float32)))
-    xn = torch.zeros(N, H, W, 8, dtype=dtype)
-    xn[..., :3] = x.permute(0, 2, 3, 1)
-    for act, code in (("relu", _lib.ACT_RELU), ("none", _lib.ACT_NONE)):
-        pc = PackedConv(w, None, bnp, 2, 3, 1, code, 0.0, dev)
-        two = ops.maxpool3x3s2(ops.conv2d(xn.to(dev), pc, tile_cfg=9))
-        one = ops.stem_pool16(xn.to(dev), pc)
-        assert one.shape == two.shape and one.dtype == dtype
-        assert torch.equal(one, two), (act, int((one != two).sum()), float((one.float() - two.float()).abs().max()))
-        y = F.conv2d(x.double(), w.to(dtype).double(), None, stride=2, padding=3)
-        gam, bet, mu, var = (v.double() for v in bnp)
-        sc = gam / torch.sqrt(var + 1e-5)
-        y = y * sc[None, :, None, None] + (bet - mu * sc)[None, :, None, None]
-        y = F.max_pool2d(torch.relu(y) if act == "relu" else y, 3, 2, 1)
-        close16(one.permute(0, 3, 1, 2), y, dtype, extra=2e-5 * float(y.abs().max()))
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
 def test_small_layers16(dev, dtype):
     from arseg_amd import _lib, ops
 
