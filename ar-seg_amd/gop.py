@@ -163,11 +163,16 @@ class GopRunner:
         nxt, prv = (self.rank + 1) % self.world, (self.rank - 1) % self.world
         stacked = (torch.stack(list(local_refs)) if len(local_refs) > 1 else local_refs[0].unsqueeze(0)).contiguous()
         inbox = self._buffer(stacked, replicas=1)
-        ops_ = [dist.P2POp(dist.isend, stacked, prv, self.group), dist.P2POp(dist.irecv, inbox, nxt, self.group)]
+        # (rehearsals on the gloo backend with device tensors: gloo's point-to-point path takes host memory -- stage through it; RCCL sends device memory)
+        via_host = stacked.is_cuda and dist.get_backend(self.group) == "gloo"
+        snd, rcv = (stacked.cpu(), torch.empty(inbox.shape, dtype=inbox.dtype)) if via_host else (stacked, inbox)
+        ops_ = [dist.P2POp(dist.isend, snd, prv, self.group), dist.P2POp(dist.irecv, rcv, nxt, self.group)]
         if self.world == 2 and self.rank == 1:      # (two ranks: both peers are the same process -- post the pair in the same order on both sides)
             ops_.reverse()
         for w in dist.batch_isend_irecv(ops_):
             w.wait()
+        if via_host:
+            inbox.copy_(rcv)
         theirs = [g for g in range(self.n_gops) if keyframe_owner(g, self.world) == nxt]
         for i, g in enumerate(theirs):
             refs[g] = inbox[i]

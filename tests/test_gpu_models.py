@@ -667,7 +667,7 @@ def _gloo_shared_gpu_worker(rank, world, port, q, mode):
     synth.load_synth_weights(lr, 1)
     hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
     n_gops = 1 if mode == "single" else world
-    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12)
+    runner = GopRunner(lambda k: ops.to_nhwc(hr(k)[-1])[0], None, n_gops=n_gops, gop=12, deal="neighbor" if mode == "neighbor" else "round_robin")
     clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
     keyframes = {g: torch.from_numpy(clips[g]["frames"][0:1]).to(dev) for g in runner.my_gops}
     fb = torch.cat([torch.from_numpy(clips[g]["frames"][d:d + 1]) for g, d in runner.plan]).to(dev)
@@ -684,7 +684,7 @@ def _gloo_shared_gpu_worker(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["batched", "single"])
+@pytest.mark.parametrize("mode", ["batched", "single", "neighbor"])
 def test_two_ranks_on_one_gpu_gloo_match_single_process(dev, mode):
     """GopRunner.run_overlapped on the HIP path with the exchange over gloo, two processes sharing ONE GPU -- each rank's
     outputs equal, bit for bit, what a single process computes for the same frames (same batch, same launch plans).  Covers what the
@@ -695,7 +695,7 @@ def test_two_ranks_on_one_gpu_gloo_match_single_process(dev, mode):
 
     from arseg_amd import evaluation as ev
     from arseg_amd import ops, synth
-    from arseg_amd.gop import frame_plan
+    from arseg_amd.gop import frame_plan, neighbor_plan
     from arseg_amd.model import PSPNet, PSPNetWithFuse
 
     world = 2
@@ -722,7 +722,7 @@ def test_two_ranks_on_one_gpu_gloo_match_single_process(dev, mode):
         hr, lr = hr.to(dev).eval(), lr.to(dev).eval()
         n_gops = 1 if mode == "single" else world
         clips = {g: synth.make_clip(g, H, W, gop=12) for g in range(n_gops)}
-        plans = frame_plan(n_gops, 12, world)
+        plans = neighbor_plan(n_gops, 12, world) if mode == "neighbor" else frame_plan(n_gops, 12, world)      # (r6) the contiguous-run deal: one send / receive
         seen = set()
         with torch.no_grad():
             refs = {g: ops.to_nhwc(hr(torch.from_numpy(clips[g]["frames"][0:1]).to(dev))[-1])[0] for g in range(n_gops)}
