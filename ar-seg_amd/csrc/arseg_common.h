@@ -46,12 +46,21 @@ __device__ __forceinline__ float arseg_h2f(uint16_t v) {
 }
 template <bool BF>
 __device__ __forceinline__ uint16_t arseg_f2h(float x) {
+    // (r6) bf16: the hardware conversion of gfx950 (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN) instead of the integer sequence of
+    // rounds 2-5 (and / compare / add / shift: ~8 VALU per value -- the epilogue arithmetic of the bf16 stem kernel was as long as its MFMAs)
+    if constexpr (BF) return __builtin_bit_cast(uint16_t, (__bf16)x);
+    else return __builtin_bit_cast(uint16_t, (_Float16)x);
+}
+// two values -> one packed dword (low half = a): one v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free v_cvt_pk for fp16
+template <bool BF>
+__device__ __forceinline__ unsigned arseg_f2h_pair(float a, float b) {
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
     if constexpr (BF) {
-        const unsigned u = __float_as_uint(x);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);      // NaN stays NaN
-        return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, bf16x2_));
     } else {
-        return __builtin_bit_cast(uint16_t, (_Float16)x);
+        typedef _Float16 h16x2_ __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_{a, b}, h16x2_));
     }
 }
 

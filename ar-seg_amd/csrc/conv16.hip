@@ -14,6 +14,9 @@
 //   * epilogue through LDS: the fp32 accumulators are transposed into [pixel][co] rows so that scale / bias / residual / activation
 //     run on 8 consecutive channels and the store is a coalesced 16-byte vector of a full NHWC row.
 #include "arseg_common.h"
+#ifndef STEM_ABL
+#define STEM_ABL 0          // dev builds (tools/bench_stem16.py): 1 = no output stores, 2 = one K step instead of 25, 4 = the patch is loaded once
+#endif
 
 namespace {
 
@@ -46,13 +49,13 @@ __device__ __forceinline__ f32x16 mfma16(const u32x4 a, const u32x4 b, const f32
     else return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
 }
 
+// activation as arithmetic on two uniform parameters (no switch per element: the epilogues apply it to 32-64 values per lane, and the four-way
+// branch per value made them as long as the MFMAs of a short-K tile): none / relu / prelu = max(v >= 0 ? v : v * s, lo) with (s, lo) = (1, -inf) /
+// (1, 0) / (slope, -inf); sigmoid keeps its (uniform) branch
 __device__ __forceinline__ float act_apply(float v, int act, float slope) {
-    switch (act) {
-        case ARSEG_ACT_RELU: return fmaxf(v, 0.0f);
-        case ARSEG_ACT_PRELU: return v >= 0.0f ? v : v * slope;
-        case ARSEG_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
-        default: return v;
-    }
+    if (act == ARSEG_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
+    const float s = act == ARSEG_ACT_PRELU ? slope : 1.0f, lo = act == ARSEG_ACT_RELU ? 0.0f : -INFINITY;
+    return fmaxf(v >= 0.0f ? v : v * s, lo);
 }
 
 template <bool BF, int CO_T, int BK>      // BK: K step (32 | 64 halves); LDS rows carry 8 halves of padding (ds_read_b128 of 32 rows conflict free)
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(256, 2) void conv16_stem_kernel(const Conv16Params 
         __syncthreads();                                      // the previous tile's patch is no longer read (and the weights are in place)
         patch_store();
         __syncthreads();
-        if (tile + (int)gridDim.x < ntiles) patch_load(tile + gridDim.x);
+        if (!(STEM_ABL & 4) && tile + (int)gridDim.x < ntiles) patch_load(tile + gridDim.x);
         f32x16 acc[2][2];                                     // [co tile][pixel row of the wave]
 #pragma unroll
         for (int a = 0; a < 2; ++a)
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void conv16_stem_kernel(const Conv16Params 
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 #pragma unroll 5
-        for (int j = 0; j < 25; ++j) {
+        for (int j = 0; j < ((STEM_ABL & 2) ? 1 : 25); ++j) {
             const int t = 2 * j + lh, tc = min(t, 48), r = (tc * 37) >> 8, sx = tc - 7 * r;      // tap (r, sx); t == 49 multiplies zero weights
             u32x4 a[2], b[2];
 #pragma unroll
@@ -519,11 +522,16 @@ __global__ __launch_bounds__(256, 2) void conv16_stem_kernel(const Conv16Params 
 #pragma unroll
                 for (int k = 0; k < 2; ++k) acc[i][k] = mfma16<BF>(a[i], b[k], acc[i][k]);
         }
-        // epilogue: lane = pixel (column li of output row 2*wave + k), accumulator rows = channels (r&3) + 8*(r>>2) + 4*lh (+32 i)
+        // epilogue: lane = pixel (column li of output row 2*wave + k), accumulator rows = channels (r&3) + 8*(r>>2) + 4*lh (+32 i).
+        // (r6, tools/bench_stem16.py with -DSTEM_ABL: of 124 us per 11-frame batch the MFMA loop was 40 and this epilogue 59 -- its ARITHMETIC, not its
+        // 8-byte stores: a software bf16 rounding (~8 VALU per value) and a four-way activation switch per value.  With v_cvt_pk_bf16_f32 and the
+        // branch-free activation: 106-108 us.  Measured and not kept: the same rows laid out in LDS and stored as contiguous 16-byte pieces (108.4 against
+        // 109-111 us: the stores were never the cost), barriers that leave the stores in flight (no change).)
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int oy = ty0 + 2 * wave + k, ox = tx0 + li;
             if (oy >= p.Ho || ox >= p.Wo) continue;
+            if ((STEM_ABL & 1) && acc[0][k][0] != 12345.678f) continue;
             uint16_t *dst = p.out + (((size_t)img * p.Ho + oy) * p.Wo + ox) * p.out_ld;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
