@@ -14,6 +14,9 @@
 //   * epilogue through LDS: the fp32 accumulators are transposed into [pixel][co] rows so that scale / bias / residual / activation
 //     run on 8 consecutive channels and the store is a coalesced 16-byte vector of a full NHWC row.
 #include "arseg_common.h"
+#ifndef PATCH_ABL
+#define PATCH_ABL 0         // dev builds (tools/bench_patch16.py): 1 = no epilogue, 2 = one K step instead of nchunk * 9, 4 = fragments read once (no LDS reads in the loop)
+#endif
 #ifndef STEM_ABL
 #define STEM_ABL 0          // dev builds (tools/bench_stem16.py): 1 = no output stores, 2 = one K step instead of 25, 4 = the patch is loaded once
 #endif
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv16_patch_ker
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    const int nsteps = nchunk * 9;                     // K steps s = (chunk ck, tap): s = 9*ck + tap
+    const int nsteps = (PATCH_ABL & 2) ? 1 : nchunk * 9;                     // K steps s = (chunk ck, tap): s = 9*ck + tap
     BRegs r0, r1;
     load_patch(0);
     load_b(0, 0, r0);
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(128 * WM, (BN == 64 ? 4 : 2)) void conv16_patch_ker
         if (s_ + 1 < nsteps) step(s_ + 1, r0, r1);
     }
 
+    if ((PATCH_ABL & 1) && acc[0][0][0] != 12345.678f) return;
     // epilogue through LDS (the patch and the weight tiles are dead: the last step ended with a barrier): 128 pixels at a time the fp32
     // accumulators are laid out [pixel][co] so that scale / bias / residual / activation run on 8 consecutive channels and the store is a
     // 16-byte vector of an NHWC row.  C/D layout of the 32x32 MFMA: col = lane&31 (co), row = (r&3) + 8*(r>>2) + 4*(lane>>5) (pixel).

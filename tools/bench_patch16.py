@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The patch-resident 16-bit 3x3 kernel (arseg_conv2d16_fwd, tile_cfg 5..8) on the 3x3 stride-1 layer shapes of the BiSeNet bench
-configurations, every tile_cfg timed alone with HIP events (tile_cfg the library does not know are skipped: 10 / 11 were the round-5 experiment
-with 64 x 64 wave tiles, profiles/r05_patch16_wave_tiles_ab.json):
+configurations, every tile_cfg timed alone with HIP events (5..8: the 4 x 64 / 2 x 64 pixel tiles, 10..13: the squarer tiles of round 6; with
+ARSEG_HIP_LIB pointing at a -DPATCH_ABL=<bits> build the ablations that say where the kernel's time goes):
 
     python tools/bench_patch16.py [--dtype bf16|f16] [--json FILE]
 
@@ -24,7 +24,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--json")
+    ap.add_argument("--cfgs", default="1,2,3,4,5,6,7,8,10,11,12,13")
+    ap.add_argument("--shapes", type=int, default=0, help="only the first n shapes")
     args = ap.parse_args()
+    cfgs = tuple(int(c) for c in args.cfgs.split(","))
     from arseg_amd import _lib, ops
     from arseg_amd.packing import PackedConv
 
@@ -32,14 +35,14 @@ def main():
     sdt = torch.bfloat16 if args.dtype == "bf16" else torch.float16
     g = np.random.Generator(np.random.PCG64(5))
     rows = []
-    for (N, H, W, Cin, Cout) in SHAPES:
+    for (N, H, W, Cin, Cout) in (SHAPES[:args.shapes] if args.shapes else SHAPES):
         w = torch.from_numpy((g.standard_normal((Cout, Cin, 3, 3)) * np.sqrt(2.0 / (9 * Cin))).astype(np.float32))
         pc = PackedConv(w, None, (torch.ones(Cout), torch.zeros(Cout), torch.zeros(Cout), torch.ones(Cout)), 1, 1, 1, _lib.ACT_RELU, 0.0, dev)
         x = torch.from_numpy(g.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dev).to(sdt)
         res = torch.from_numpy(g.standard_normal((N, H, W, Cout)).astype(np.float32)).to(dev).to(sdt)
         flops = 2.0 * N * H * W * Cout * 9 * Cin
         per = {}
-        for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 10, 11):
+        for cfg in cfgs:
             try:
                 ops.conv2d(x, pc, residual=res, tile_cfg=cfg)
                 per[cfg] = 1e3 * ops._time(lambda: ops.conv2d(x, pc, residual=res, tile_cfg=cfg), reps=20)
