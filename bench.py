@@ -220,7 +220,7 @@ def main():
     # ---- the other single-GPU BASELINE shapes, driver-timed in the same line (short runs)
     if world == 1 and args.config == "psp" and not args.no_variants and not args.loopback:
         result["variants"] = {}
-        for name in ("psp_f32", "psp_reference_outputs", "psp2k", "bise_bf16", "bise03_fp16"):
+        for name in ("psp_f32", "psp_reference_outputs", "psp2k", "bise_bf16", "bise03_fp16", "semseg"):      # semseg = SURVEY 8f row 1 (Cityscapes PSPNet-18)
             try:
                 if name == "psp_f32":          # the headline workload with the reference's own arithmetic: fp32 MFMA
                     a32 = argparse.Namespace(**{**vars(args), "conv_math": "f32"})
