@@ -12,6 +12,9 @@
 // tilesY = ceil(ceil(H/d)/4).  Threads run along channels (coalesced 4-byte accesses, 36 registers of patch per thread).
 // fp32 throughout; the transform constants grow the rounding error to ~1e-5 relative (vs 1e-6 for the direct form).
 #include "arseg_common.h"
+#ifndef WINO_NT_LOADS
+#define WINO_NT_LOADS 1
+#endif
 
 namespace {
 
@@ -207,7 +210,13 @@ __global__ __launch_bounds__(256) void wino43_output_kernel(const float *__restr
 #pragma unroll
         for (int i = 0; i < 6; ++i)
 #pragma unroll
-            for (int j = 0; j < 6; ++j) m[i][j] = *reinterpret_cast<const F *>(M + ((size_t)(i * 6 + j) * g.T + t) * C + c);
+            for (int j = 0; j < 6; ++j) {
+#if WINO_NT_LOADS
+                m[i][j] = __builtin_nontemporal_load(reinterpret_cast<const F *>(M + ((size_t)(i * 6 + j) * g.T + t) * C + c));
+#else
+                m[i][j] = *reinterpret_cast<const F *>(M + ((size_t)(i * 6 + j) * g.T + t) * C + c);
+#endif
+            }
         F tmp[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {            // A^T m : columns
