@@ -41,6 +41,7 @@ struct Conv16Params {
     int patch_tw, patch_l2tw, tiles_m;      // patch-resident 3x3 kernel: tile width (a power of two), its log2, pixel tiles
     int nsplit, kt_per_split;        // split-K: blockIdx.y = K slice, fp32 partial sums to `ws` [nsplit][M][Cout], epilogue in the reduce kernel
     float *ws;
+    int log2Cin, inv_S;              // (r6) Cin = 1 << log2Cin (or -1), 65536 / S + 1: the K -> (tap, channel) decode of the implicit GEMM without divisions
 };
 
 constexpr int PIX_T = 128, KPAD = 64;                  // Kpad16 is a multiple of 64 (both K steps divide it)
@@ -114,9 +115,18 @@ __global__ __launch_bounds__(256) void conv16_kernel(const Conv16Params p) {
 
     struct Regs { u32x4 a[RA], b[RB]; };
     auto load = [&](int kt, Regs &r) {
+        // k -> (tap, channel) -> (filter row, column).  (r6) Two integer divisions by run-time values per thread and K step (~50 VALU) stood beside 4-8
+        // MFMAs per wave and step; with Cin a power of two >= BK the tap is UNIFORM over the workgroup (a K step never straddles a tap) and
+        // comes from scalar shifts, the filter row from a multiply-high (exact for taps < 64)
         const int k = kt * BK + chunk * 8;
-        const int tap = k / p.Cin, ci = k - tap * p.Cin;
-        const int fr = tap / p.S, fs = tap - fr * p.S;
+        int tap, ci;
+        if (p.log2Cin >= 0 && (1 << p.log2Cin) >= BK) {
+            const int kb = kt * BK;
+            tap = kb >> p.log2Cin; ci = (kb & ((1 << p.log2Cin) - 1)) + chunk * 8;
+        } else {
+            tap = k / p.Cin; ci = k - tap * p.Cin;
+        }
+        const int fr = (tap * p.inv_S) >> 16, fs = tap - fr * p.S;
         const int dy = fr * p.dil, dx = fs * p.dil;
         const int tapoff = ((dy * p.W + dx) * p.in_ld + ci) * 2;
         const bool kok = k < p.K;
@@ -670,6 +680,10 @@ extern "C" int arseg_conv2d16_fwd(const arseg_conv_desc *d, int dtype, const voi
     p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.in_ld = d->in_ld; p.Ho = Ho; p.Wo = Wo; p.Cout = d->Cout; p.out_ld = d->out_ld;
     p.res_ld = d->res_ld; p.R = d->R; p.S = d->S; p.stride = d->stride; p.pad = d->pad; p.dil = d->dil;
     p.K = d->R * d->S * d->Cin; p.Kpad = (p.K + KPAD - 1) / KPAD * KPAD; p.act = d->act; p.slope = d->prelu_slope;
+    p.log2Cin = -1;
+    for (int b = 3; b < 16; ++b) if (d->Cin == (1 << b)) p.log2Cin = b;
+    p.inv_S = 65536 / d->S + 1;
+    if (d->R * d->S > 64) return ARSEG_EUNSUPPORTED;          // (the multiply-high filter-row decode is exact for taps < 64: up to 7 x 7 and 8 x 8)
     const long long M = (long long)d->N * Ho * Wo;
     const size_t in_bytes = (size_t)d->N * d->H * d->W * d->in_ld * 2, w_bytes = (size_t)d->Cout * p.Kpad * 2;
     if (M >= (1ll << 31) || in_bytes >= (1ull << 31) || w_bytes >= (1ull << 31)) return ARSEG_EUNSUPPORTED;       // 32-bit buffer offsets
