@@ -491,6 +491,8 @@ def run_config(args, config, steps, warmup, world, rank, dev, backend, full):
         "ms_per_step": 1e3 * elapsed / steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": storage if storage != "f32" else ("f16" if args.conv_math == "f16" else "f32"), "data": "synthetic",
+        "data_note": f"seeded synthetic GOP-12 clip(s), random-init (seeded) weights; the {len(streams)} lanes replay the SAME clip of this rank (its inputs, ~75 MB at "
+                     "the headline size, stay cache-warm across lanes: immaterial beside the ~14 GB of HBM traffic of a GOP step); every lane has its own activations and outputs",
         "conv_math": args.conv_math + {"f16x3": " (fp32 operands split into hi+lo fp16, 3 fp16 MFMAs per product, fp32 accumulate)",
                                        "f32": " (fp32 MFMA)", "f16": " (REDUCED PRECISION: plain fp16 operands, fp32 accumulate; not the headline)"}[args.conv_math],
         "streams": len(streams), "executor": ("hip-graph replay (%d lanes, one graph per lane on its own stream)" if not args.joined_graph else "hip-graph replay (%d GOP steps per replay on forked streams)") % len(streams) if gop_graph is not None else "eager launches",
